@@ -1,0 +1,245 @@
+/*
+ * rtx.h — C ABI of librt_hip.so, the MI355X (gfx950) ray→scene query engine that replaces the
+ * hot path of deggua/raytracer:  Scene_ClosestHit (src/world/scene.c:100) → KDTree_HitAt
+ * (src/rt/accelerators/kdtree.c:572) → Surface_HitAt (src/world/object.c:7) → Material_Bounce
+ * (src/world/object.c:64), driven by RayColor/RenderPixel (src/rt/renderer.c:54-111).
+ *
+ * The reference has no FFI: the seam is its render loop (Render_Start/Render_Done,
+ * src/rt/renderer.h:19-22).  A caller flattens the host scene (kd-tree nodes, leaf index runs,
+ * triangles, spheres, planes, materials, textures) into the pools of `rtx_scene_desc`, uploads them
+ * once with rtx_scene_create and renders whole frames with rtx_render.  INTEGRATION.md shows the
+ * shim a reference maintainer adds next to Render_Start.
+ *
+ * Conventions: plain C, no C++ types, no exceptions, no abort(); every function returns 0 (RTX_OK)
+ * or a negative RTX_E_* code and sets a thread-local message readable through rtx_last_error().
+ * All multi-byte values are little-endian; all indices are u32; all floats IEEE binary32.
+ * The library fails loudly (RTX_E_NO_DEVICE) when no gfx950 device is visible: there is no CPU path.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+
+enum {
+    RTX_OK            = 0,
+    RTX_E_INVALID     = -1, /* bad argument / malformed scene description        */
+    RTX_E_NO_DEVICE   = -2, /* no HIP device, or the requested ordinal is absent  */
+    RTX_E_HIP         = -3, /* a HIP runtime call failed (message has the detail) */
+    RTX_E_NOMEM       = -4, /* host or device allocation failed                   */
+    RTX_E_LIMIT       = -5, /* a documented size limit was exceeded               */
+    RTX_E_EMPTY_SCENE = -6, /* no bounded primitive: the reference dereferences a NULL tree
+                               here (src/world/scene.c:109,159-163); we refuse instead      */
+};
+
+/* Material kinds: values match Material_Type (src/rt/materials.h:17-34). */
+enum {
+    RTX_MAT_DIFFUSE          = 0,
+    RTX_MAT_METAL            = 1,
+    RTX_MAT_DIELECTRIC       = 2,
+    RTX_MAT_DIFFUSE_LIGHT    = 3,
+    RTX_MAT_SKYBOX           = 4,
+    RTX_MAT_DISNEY_DIFFUSE   = 5,
+    RTX_MAT_DISNEY_METAL     = 6,
+    RTX_MAT_DISNEY_GLASS     = 7,
+    RTX_MAT_DISNEY_CLEARCOAT = 8,
+    RTX_MAT_DISNEY_SHEEN     = 9,
+    RTX_MAT_DISNEY_BSDF      = 10,
+};
+
+/* One material, 64 bytes.  Mirrors `Material` (src/rt/materials.h:78-90) with the Texture*
+ * replaced by an index into the texture table (-1 = none; clearcoat has none).
+ *   simple kinds: p[0] = fuzz (metal) | refractive index (dielectric) | brightness (light)
+ *   Disney kinds: p[0..11] = subsurface, specular, roughness, specular_tint, anistropic,
+ *                 sheen_tint, clearcoat_gloss, eta, w.clearcoat, w.sheen, w.metallic, w.specular
+ *                 (field order of Material_Disney_BSDF, src/rt/materials.h:59-76)            */
+typedef struct rtx_material {
+    uint32_t type;
+    int32_t  tex;
+    float    p[14];
+} rtx_material;
+
+/* A texture = linear-light f32 RGB image (ImageColor, src/gfx/image.h:23-29), row-major,
+ * row 0 first, 3 floats per texel, starting at tex_data[3*offset]. */
+typedef struct rtx_texture_desc {
+    uint32_t width;
+    uint32_t height;
+    uint64_t offset; /* in texels */
+} rtx_texture_desc;
+
+/* Camera block = `Camera` (src/world/camera.h:6-13), 88 bytes, produced by Camera_New. */
+typedef struct rtx_camera {
+    float origin[3];
+    float bottom_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+} rtx_camera;
+
+/* leaf_ref encoding: bit 31 = primitive pool (0 triangle, 1 sphere), bits 0-30 = pool index. */
+#define RTX_REF_SPHERE 0x80000000u
+/* prim_id convention of rtx_trace_closest: index into the reference's kdObjects
+ * array for bounded hits, RTX_ID_UNBOUNDED|index into unboundObjs for plane hits, -1 for a miss. */
+#define RTX_ID_UNBOUNDED 0x80000000u
+#define RTX_ID_MISS      0xFFFFFFFFu
+
+/* Flattened scene.  Arrays named "[c*N + i]" are component-major SoA: component c of item i.
+ * The caller keeps ownership; rtx_scene_create copies everything it needs.
+ *
+ * kd-tree (KDNode, src/rt/accelerators/kdtree.c:71-114, re-packed to 8 bytes):
+ *   node_w0[i]  = f32 bits of `split` (internal) or `len` (leaf)
+ *   node_w1[i]  = type<<30 | index     type 0/1/2 = split axis X/Y/Z, 3 = leaf
+ *                 index = leftIndex (internal; right child is i+1, kdtree.c:153-155,507)
+ *                       | first entry in leaf_ref (leaf)
+ *   leaf_ref[k] = objPtrs (kdtree.c:130,185-193) with each Object* replaced by pool|index     */
+typedef struct rtx_scene_desc {
+    uint32_t abi_version; /* RTX_ABI_VERSION */
+    uint32_t n_nodes, n_refs, root_index;
+    uint32_t n_tris, n_spheres, n_planes;
+    uint32_t n_materials, n_textures;
+    uint32_t max_depth; /* kd-tree depth bound (kdtree.c:408) + 1: sizes the traversal stack */
+
+    const uint32_t* node_w0;
+    const uint32_t* node_w1;
+    const uint32_t* leaf_ref;
+
+    /* triangles (Triangle/Vertex, src/rt/surfaces.h:29-37) */
+    const float*    tri_pos; /* [c*T+i], c = 3*vertex+axis, 9 components  */
+    const float*    tri_nrm; /* [c*T+i], 9 components, NOT normalised      */
+    const float*    tri_uv;  /* [c*T+i], c = 2*vertex+{u,v}, 6 components  */
+    const uint8_t*  tri_mat; /* material index                             */
+    const uint32_t* tri_obj; /* index in the reference's kdObjects array   */
+
+    /* spheres (Sphere, surfaces.h:24-27): [c*S+i], c = cx,cy,cz,r */
+    const float*    sph;
+    const uint8_t*  sph_mat;
+    const uint32_t* sph_obj;
+
+    /* planes (Plane, surfaces.h:39-42), the "unbounded" list of Scene_Prepare
+     * (src/world/scene.c:150-156), in list order: [c*P+i], c = nx,ny,nz,px,py,pz */
+    const float*   plane;
+    const uint8_t* plane_mat;
+
+    const rtx_material*     materials;
+    const rtx_texture_desc* textures;
+    const float*            tex_data;
+    uint64_t                tex_texels; /* total texels in tex_data */
+    int32_t                 skybox_tex[6]; /* xpos,xneg,ypos,yneg,zpos,zneg (src/world/skybox.c:30) */
+} rtx_scene_desc;
+
+typedef struct rtx_scene rtx_scene; /* opaque; one per (scene, device) */
+
+#define RTX_MAX_DEPTH 64
+
+/* Frame partition for multi-GPU.  Rows are grouped in bands of `band_rows`; this call
+ * renders band b iff b % band_world == band_rank.  Samples [sample_begin, sample_end) of every
+ * rendered pixel are traced; the RNG stream of a path is keyed by its GLOBAL (pixel, sample):
+ *   Random_Seed(seed_lo ^ (pixel_index*spp + sample), seed_hi)     (src/math/random.c:78-85)
+ * so the union over ranks equals the single-GPU sample set. */
+typedef struct rtx_render_params {
+    uint32_t width, height;
+    uint32_t spp;       /* samples per pixel of the whole job (argv[1] of the reference) */
+    uint32_t max_depth; /* max_ray_depth of Render_Start (argv[2]); counts rays, not bounces */
+    uint64_t seed_lo, seed_hi;
+    uint32_t sample_begin, sample_end; /* 0,0 = all */
+    uint32_t band_rows;                /* 0 = whole frame on this device */
+    uint32_t band_rank, band_world;
+    uint32_t flags;
+    uint64_t max_paths_in_flight; /* 0 = auto (whole assigned frame if it fits the HBM budget) */
+} rtx_render_params;
+
+#define RTX_RENDER_COUNT_VISITS 1u /* also count kd-tree visits (slower kernel variant)      */
+#define RTX_RENDER_PIXEL_CENTRES 2u /* replace the two jitter draws by 0.5 (config-1 ray set A) */
+
+typedef struct rtx_stats {
+    uint64_t rays_total;
+    uint64_t rays_at_depth[RTX_MAX_DEPTH];
+    uint64_t camera_paths;
+    uint64_t visits_inner, visits_leaf, visits_prim; /* only with RTX_RENDER_COUNT_VISITS */
+    uint64_t hits_shaded;                            /* rays that reached Material_Bounce   */
+    double   ms_total;                               /* whole call, device time (events)    */
+    double   ms_trace;                               /* sum over closest-hit launches        */
+    double   ms_shade;
+    double   ms_raygen;
+    double   ms_resolve;
+    uint32_t trace_launches;
+    uint32_t passes; /* slabs */
+} rtx_stats;
+
+/* ---- library ---- */
+int         rtx_abi_version(void);
+const char* rtx_last_error(void);
+int         rtx_device_count(int* count);
+
+/* ---- scene hand-over: replaces the pointer the render workers read (ctx->scene,
+ *      src/rt/renderer.c:151) with device-resident pools ---- */
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
+int rtx_scene_destroy(rtx_scene* scene);
+int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
+
+/* ---- ray-level parity seam: batched Scene_ClosestHit (src/world/scene.h:12).
+ * Host pointers, interleaved xyz.  dir need not be normalised: Ray_Make (src/rt/ray.c:3-16)
+ * is applied on the device.  Outputs may be NULL.  `stats` may be NULL. ---- */
+int rtx_trace_closest(rtx_scene* scene, size_t n, const float* origin_xyz, const float* dir_xyz,
+                      uint32_t* prim_id, float* t, float* position_xyz, float* normal_xyz, float* uv,
+                      uint8_t* front_face, rtx_stats* stats, uint32_t flags);
+
+/* Same query on device-resident SoA rays (ox,oy,oz,dx,dy,dz each n floats at rays+c*n), already
+ * normalised by a previous Ray_Make; writes prim ref/t/u/v (4 x n dwords, SoA) to `hits`.
+ * Asynchronous on `stream` (a hipStream_t); this is the entry bench.py times. */
+int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, uint32_t* d_hits,
+                             void* stream, uint32_t flags, uint64_t* d_visit_counters);
+
+/* ---- frame-level seam: replaces Render_Worker/RenderTile/RenderPixel/RayColor
+ *      (src/rt/renderer.c:54-178).  Blocking.  bgr_out = ImageRGB.pix (RGB{b,g,r},
+ *      src/gfx/color.h:19-23; row 0 = bottom scanline), width*height*3 bytes, host memory, may be
+ *      NULL.  accum_out = width*height*3 f32, host memory, per-pixel SUM of the traced samples'
+ *      RayColor in r,g,b order (rows not assigned to this call are left untouched), may be NULL. */
+int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,
+               uint8_t* bgr_out, float* accum_out, rtx_stats* stats);
+
+/* Device-output variant for multi-GPU: d_accum (f32 x 3 x W x H, device) receives the per-pixel
+ * sums of the rows/samples assigned to this call and must be zero-filled by the caller beforehand;
+ * the caller reduces it across ranks (RCCL) and then calls rtx_resolve_device. Runs on `stream`
+ * and synchronises it before returning (stats need the event times). */
+int rtx_render_device(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,
+                      float* d_accum, void* stream, rtx_stats* stats);
+
+/* RenderPixel's tail (src/rt/renderer.c:109-110): avg = sum * (1.0f/spp); RGB_FromColor
+ * (src/gfx/color.c:18-29,49-56) → BGR u8.  d_accum and d_bgr are device pointers. */
+int rtx_resolve_device(rtx_scene* scene, const float* d_accum, uint32_t width, uint32_t height,
+                       uint32_t spp, uint8_t* d_bgr, void* stream);
+
+/* ---- unit-level parity seams (host pointers; small batches) ---- */
+
+/* RenderPixel jitter + Camera_GetRay + Ray_Make (src/rt/renderer.c:101-104, src/world/camera.c:34-49)
+ * for paths (pixel_index[i], sample[i]); outputs origin/dir (interleaved xyz) and the RNG state
+ * after the four draws. */
+int rtx_camera_rays(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,
+                    size_t n, const uint32_t* pixel_index, const uint32_t* sample, float* origin_xyz,
+                    float* dir_xyz, uint32_t* rng_state4);
+
+/* Random_Seed(seed_lo, seed_hi) then `n` Random_Unilateral() draws (src/math/random.c:78-105). */
+int rtx_rng_unilateral(rtx_scene* scene, uint64_t seed_lo, uint64_t seed_hi, size_t n, float* out);
+
+/* Material_Bounce (src/world/object.c:64-143) for n independent (ray, hit) records against
+ * material `mat_index`, each with its own RNG state (in/out).  cont[i] = the bool returned. */
+int rtx_material_bounce(rtx_scene* scene, uint32_t mat_index, size_t n, const float* ray_dir_xyz,
+                        const float* hit_position_xyz, const float* hit_normal_xyz, const float* hit_uv,
+                        const uint8_t* front_face, uint32_t* rng_state4, float* surface_rgb,
+                        float* emitted_rgb, float* out_origin_xyz, float* out_dir_xyz, uint8_t* cont);
+
+/* Skybox_ColorAt (src/world/skybox.c:66-134) for n directions. */
+int rtx_skybox_color(rtx_scene* scene, size_t n, const float* dir_xyz, float* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */
