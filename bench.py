@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole frame of the hot path (raygen → [closest-hit → shade/bounce] x depth →
+resolve) over synthetic input: the dragon stand-in scene (BASELINE.json's `metric` is quoted on
+dragon.obj, which the reference does not ship — see raytracer_amd/assets.py), Disney
+glass+clearcoat mixture, light sphere, skybox-material ground plane, 1920x1080, 64 spp, depth 8.
+Scene pools are resident in HBM before the timed region; the frame is rendered into a device
+f32 accumulation buffer, reduced to rank 0 (RCCL, only for N > 1) and tone-mapped on rank 0.
+
+For N > 1 launch as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+one rank per GPU; the same frame is split by interleaved 16-row bands ("strong" scaling: the total
+work is fixed), timed between barriers, MAX over ranks; rank 0 prints ONE JSON line.
+
+The oracle / reference binaries are used only for the `cpu_baseline` leg (rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def alg_bytes(vi, vl, vp, rays):
+    """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d):
+    8 B per inner node + 8 B per leaf + (4 B leaf ref + 36 B vertex positions) per primitive test
+    + 64 B ray record read + 44 B hit record write per ray."""
+    return 8 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
+
+
+def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):
+    """Time the reference's own multithreaded renderer (oracle/_ref/ref_perf: unmodified sources,
+    release flags, NUM_HYPERTHREADS = 16 worker threads) on a bounded sample of the workload."""
+    from oracle import binding as O
+    from raytracer_amd import assets, scenes
+    out = {"value": None, "unit": "Mrays/s", "cores": 16, "kind": "reference",
+           "sample": "%s %dx%d %d spp depth %d (reduced frame of the same scene, full spp)" % (scene_name, w, h, spp, depth)}
+    try:
+        r = O.ref_run("perf", scenes.write_recipe(scene_name), assets.cache_dir(), "bench", w, h, spp, depth, timeout=900)
+        rays = rays_fn(w, h, spp, depth)
+        out.update(value=rays / r["seconds"] / 1e6, seconds=r["seconds"], rays=rays, s_per_full_frame_extrapolated=None)
+    except Exception as e:  # binary absent or cannot run on this host: fall back to the CPU port (oracle)
+        from raytracer_amd import hip
+        sc = scenes.build(scene_name)
+        p = hip.make_params(w, h, max(1, spp // 8), depth)
+        t0 = time.time()
+        _, _, rays = O.render(sc.desc, sc.rtx_camera(), p, threads=16, want_bgr=False)
+        dt = time.time() - t0
+        out.update(kind="port", value=float(rays.sum()) / dt / 1e6, seconds=dt, rays=int(rays.sum()),
+                   sample=out["sample"].replace("%d spp" % spp, "%d spp" % max(1, spp // 8)), note="ref_perf unavailable: %s" % str(e)[:120])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="dragon1")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--split", default="tile", choices=["tile", "sample"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-bmp", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    from raytracer_amd import hip, scenes
+    from raytracer_amd.distributed import FramePlan, reduce_to_rank0
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to benchmark)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    sc = scenes.build(args.scene)
+    ds = hip.DeviceScene(sc.desc, local_rank)
+    cam = sc.rtx_camera()
+    plan = FramePlan(args.width, args.height, args.spp, args.depth, seed=(1, 2), split=args.split)
+    params = plan.rank_params(rank, world)
+    accum = torch.zeros(args.height, args.width, 3, dtype=torch.float32, device=dev)
+    bgr = torch.zeros(args.height, args.width, 3, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def frame(p):
+        accum.zero_()
+        st = ds.render_device(cam, p, accum.data_ptr(), stream)
+        reduce_to_rank0(accum)
+        if rank == 0:
+            ds.resolve_device(accum.data_ptr(), args.width, args.height, args.spp, bgr.data_ptr(), stream)
+        return st
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # untimed counted pass: kd-tree visit totals of this rank's share (deterministic per frame)
+    p_count = plan.rank_params(rank, world)
+    p_count.flags |= hip.RTX_RENDER_COUNT_VISITS
+    st_count = frame(p_count)
+    for _ in range(args.warmup):
+        frame(params)
+    barrier()
+    t0 = time.perf_counter()
+    stats = [frame(params) for _ in range(args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+
+    rays_rank = float(sum(s["rays_total"] for s in stats))
+    vals = torch.tensor([dt, rays_rank, sum(s["ms_trace"] for s in stats), float(sum(s["trace_launches"] for s in stats)),
+                         float(alg_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["rays_total"])),
+                         float(st_count["rays_total"]), float(st_count["visits_inner"]), float(st_count["visits_leaf"]), float(st_count["visits_prim"]),
+                         sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats)],
+                        dtype=torch.float64, device=dev)
+    tmax = vals[:1].clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        t = float(tmax[0])
+        v = vals.tolist()
+        rays_total, ms_trace, launches, bytes_frame, rays_frame = v[1], v[2], v[3], v[4], v[5]
+        # roofline of the dominant kernel (closest hit): algorithmic bytes per launch / mean launch time.
+        # ms_trace sums HIP-event spans recorded around each launch on the stream it runs on.
+        launches_per_frame = launches / args.steps / world
+        alg_per_launch = bytes_frame / world / max(launches_per_frame, 1)
+        ms_per_launch = ms_trace / max(launches, 1)
+        achieved = alg_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        traffic = None
+        tj = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tj):  # measured in a separate rocprofv3 --pmc run of this same command (profiles/)
+            tr = json.load(open(tj))
+            if tr.get("workload") == "%s %dx%d %dspp d%d" % (args.scene, args.width, args.height, args.spp, args.depth) and world == 1:
+                traffic = tr.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/s and s/frame, dragon.obj 1080p 64spp, at 1/2/4/8 MI355X",
+            "value": rays_total / t / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t / args.steps, "s_per_frame": t / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dragon stand-in (bunny subdivided x%d, %d triangles), Disney glass+clearcoat, %dx%d, %d spp, depth %d, %s split"
+                                   % (int(args.scene[6:] or 1) if args.scene.startswith("dragon") else 0, sc.desc.contents.n_tris, args.width,
+                                      args.height, args.spp, args.depth, args.split),
+                       "scene": args.scene, "triangles": int(sc.desc.contents.n_tris), "kd_nodes": int(sc.desc.contents.n_nodes),
+                       "rays_per_frame": rays_frame, "rays_per_camera_path": rays_frame / (args.width * args.height * args.spp),
+                       "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame},
+                       "kernel_ms_per_frame": {"trace": ms_trace / args.steps / world, "shade": v[9] / args.steps / world,
+                                               "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_trace", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
+                         "alg_bytes_per_ray": bytes_frame / rays_frame},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            def gpu_rays(w, h, spp, depth):
+                a = torch.zeros(h, w, 3, dtype=torch.float32, device=dev)
+                s = ds.render_device(cam, hip.make_params(w, h, spp, depth, seed=(1, 2)), a.data_ptr(), stream)
+                return s["rays_total"]
+            out["cpu_baseline"] = cpu_baseline(args.scene, 480, 270, args.spp, args.depth, gpu_rays)
+        if args.save_bmp:
+            from raytracer_amd import host
+            import ctypes as C
+            img = host.ImageRGB()
+            host.lib().ImageRGB_Load_Empty(C.byref(img), args.width, args.height)
+            C.memmove(img.pix, bgr.cpu().numpy().ctypes.data, args.width * args.height * 3)
+            host.lib().ImageRGB_Save_BMP_Path(C.byref(img), args.save_bmp.encode())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ds.close()
+
+
+if __name__ == "__main__":
+    main()

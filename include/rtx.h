@@ -157,6 +157,7 @@ typedef struct rtx_render_params {
 
 #define RTX_RENDER_COUNT_VISITS 1u /* also count kd-tree visits (slower kernel variant)      */
 #define RTX_RENDER_PIXEL_CENTRES 2u /* replace the two jitter draws by 0.5 (config-1 ray set A) */
+#define RTX_TRACE_UNIT_DIR 4u /* rtx_trace_closest: dir_xyz already went through Ray_Make; use as is */
 
 typedef struct rtx_stats {
     uint64_t rays_total;

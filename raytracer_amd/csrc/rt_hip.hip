@@ -1,0 +1,999 @@
+// librt_hip.so — the C ABI of include/rtx.h on top of hand-written gfx950 kernels.
+//
+// Wavefront path tracer: the frame is cut into slabs of camera paths that live
+// in HBM as SoA queues; every bounce is  closest-hit kernel → shade/bounce kernel, the latter
+// compacting the surviving paths into the other queue with a wave ballot + one atomic per block,
+// so the next closest-hit pass again reads dense, coalesced ray records.  Each path writes its
+// final radiance exactly once (the reference's RayColor recursion only ever adds emission at the
+// end of a path: src/rt/renderer.c:54-76) into a per-path result slot; a resolve kernel then sums
+// the spp results of a pixel sequentially in sample order, like RenderPixel (renderer.c:98-110),
+// which keeps the frame deterministic — no float atomics anywhere.
+//
+// There is no CPU fallback in this library: without a HIP device every entry point fails with
+// RTX_E_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(RTX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" int         rtx_abi_version(void) { return RTX_ABI_VERSION; }
+extern "C" const char* rtx_last_error(void) { return g_err; }
+
+extern "C" int rtx_device_count(int* count)
+{
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (count) *count = 0;
+        return fail(RTX_E_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    }
+    if (count) *count = n;
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------------------------
+struct rtx_scene {
+    int                device;
+    SceneDev           dev;
+    std::vector<void*> allocs;
+    uint64_t           bytes;
+    // per-scene scratch reused across calls
+    uint64_t* d_counters; // [0..2] visits, [3] queue count, [4] shaded hits
+    hipEvent_t ev[2 * 1024];
+    int        n_ev;
+    // render workspace (path queues, hit records, per-path results): grown on demand, kept between
+    // frames so that a render loop does not pay hipMalloc/hipFree of gigabytes per frame
+    void*    ws;
+    uint64_t ws_bytes;
+};
+
+static int workspace(rtx_scene* sc, uint64_t bytes, char** out)
+{
+    if (sc->ws_bytes < bytes) {
+        if (sc->ws) (void)hipFree(sc->ws);
+        sc->ws       = nullptr;
+        sc->ws_bytes = 0;
+        hipError_t e = hipMalloc(&sc->ws, bytes);
+        if (e != hipSuccess) return fail(RTX_E_NOMEM, "cannot allocate a %llu-byte render workspace: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        sc->ws_bytes = bytes;
+    }
+    *out = (char*)sc->ws;
+    return RTX_OK;
+}
+
+template <typename T>
+static int upload(rtx_scene* sc, const T* host, size_t count, const T** out)
+{
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void*  p     = nullptr;
+    HIPCHECK(hipMalloc(&p, bytes));
+    sc->allocs.push_back(p);
+    sc->bytes += bytes;
+    if (count) HIPCHECK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return RTX_OK;
+}
+
+extern "C" int rtx_scene_destroy(rtx_scene* sc)
+{
+    if (!sc) return RTX_OK;
+    (void)hipSetDevice(sc->device);
+    for (void* p : sc->allocs) (void)hipFree(p);
+    if (sc->ws) (void)hipFree(sc->ws);
+    for (int i = 0; i < sc->n_ev; i++) (void)hipEventDestroy(sc->ev[i]);
+    delete sc;
+    return RTX_OK;
+}
+
+extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
+{
+    if (!sc || !bytes) return fail(RTX_E_INVALID, "null argument");
+    *bytes = sc->bytes;
+    return RTX_OK;
+}
+
+static int validate_desc(const rtx_scene_desc* d)
+{
+    if (!d) return fail(RTX_E_INVALID, "null scene description");
+    if (d->abi_version != RTX_ABI_VERSION) return fail(RTX_E_INVALID, "scene description ABI %u, library %d", d->abi_version, RTX_ABI_VERSION);
+    if (d->n_nodes == 0 || d->n_tris + d->n_spheres == 0)
+        return fail(RTX_E_EMPTY_SCENE, "scene has no bounded primitive / kd-tree (the reference dereferences NULL here, scene.c:109)");
+    if (d->n_nodes >= (1u << 30) || d->n_refs >= (1u << 30) || d->n_tris >= (1u << 30) || d->n_spheres >= (1u << 30) || d->n_planes >= (1u << 30))
+        return fail(RTX_E_LIMIT, "pool larger than 2^30 entries");
+    if (d->max_depth == 0 || d->max_depth > RTX_STACK) return fail(RTX_E_LIMIT, "kd-tree depth bound %u exceeds the traversal stack (%d)", d->max_depth, RTX_STACK);
+    if (d->root_index >= d->n_nodes) return fail(RTX_E_INVALID, "root index out of range");
+    if (!d->node_w0 || !d->node_w1 || (d->n_refs && !d->leaf_ref)) return fail(RTX_E_INVALID, "null kd-tree pool");
+    if (d->n_tris && (!d->tri_pos || !d->tri_nrm || !d->tri_uv || !d->tri_mat || !d->tri_obj)) return fail(RTX_E_INVALID, "null triangle pool");
+    if (d->n_spheres && (!d->sph || !d->sph_mat || !d->sph_obj)) return fail(RTX_E_INVALID, "null sphere pool");
+    if (d->n_planes && (!d->plane || !d->plane_mat)) return fail(RTX_E_INVALID, "null plane pool");
+    if (d->n_materials == 0 || !d->materials) return fail(RTX_E_INVALID, "no materials");
+    if (d->n_textures && (!d->textures || !d->tex_data)) return fail(RTX_E_INVALID, "null texture pool");
+    // every index the kernels will follow is checked here, once, on the host: a bad index on the
+    // device is a GPU fault
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        uint32_t type = d->node_w1[i] >> 30, idx = d->node_w1[i] & 0x3FFFFFFFu;
+        if (type == 3u) {
+            if ((uint64_t)idx + d->node_w0[i] > d->n_refs) return fail(RTX_E_INVALID, "leaf %u runs past the reference pool", i);
+        } else {
+            if (idx >= d->n_nodes || i + 1 >= d->n_nodes) return fail(RTX_E_INVALID, "inner node %u has a child out of range", i);
+        }
+    }
+    for (uint32_t i = 0; i < d->n_refs; i++) {
+        uint32_t r = d->leaf_ref[i];
+        if ((r & RTX_REF_SPHERE) ? ((r & 0x7FFFFFFFu) >= d->n_spheres) : (r >= d->n_tris)) return fail(RTX_E_INVALID, "leaf reference %u out of range", i);
+    }
+    for (uint32_t i = 0; i < d->n_tris; i++)
+        if (d->tri_mat[i] >= d->n_materials) return fail(RTX_E_INVALID, "triangle %u: material out of range", i);
+    for (uint32_t i = 0; i < d->n_spheres; i++)
+        if (d->sph_mat[i] >= d->n_materials) return fail(RTX_E_INVALID, "sphere %u: material out of range", i);
+    for (uint32_t i = 0; i < d->n_planes; i++)
+        if (d->plane_mat[i] >= d->n_materials) return fail(RTX_E_INVALID, "plane %u: material out of range", i);
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const rtx_texture_desc& t = d->textures[i];
+        if (t.width == 0 || t.height == 0 || t.offset + (uint64_t)t.width * t.height > d->tex_texels) return fail(RTX_E_INVALID, "texture %u out of range", i);
+    }
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rtx_material& m = d->materials[i];
+        if (m.type > RTX_MAT_DISNEY_BSDF) return fail(RTX_E_INVALID, "material %u: unknown type %u", i, m.type);
+        if (m.tex >= (int32_t)d->n_textures) return fail(RTX_E_INVALID, "material %u: texture out of range", i);
+        bool needs_tex = m.type != RTX_MAT_SKYBOX && m.type != RTX_MAT_DISNEY_CLEARCOAT;
+        if (needs_tex && m.tex < 0) return fail(RTX_E_INVALID, "material %u needs a texture", i);
+    }
+    for (int i = 0; i < 6; i++)
+        if (d->skybox_tex[i] < 0 || d->skybox_tex[i] >= (int32_t)d->n_textures) return fail(RTX_E_INVALID, "skybox face %d has no texture", i);
+    return RTX_OK;
+}
+
+extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene** out)
+{
+    if (!out) return fail(RTX_E_INVALID, "null output");
+    *out = nullptr;
+    int n = 0, rc;
+    if ((rc = rtx_device_count(&n)) != RTX_OK) return rc;
+    if (device < 0 || device >= n) return fail(RTX_E_NO_DEVICE, "device %d not present (%d visible)", device, n);
+    if ((rc = validate_desc(d)) != RTX_OK) return rc;
+    HIPCHECK(hipSetDevice(device));
+
+    rtx_scene* sc = new rtx_scene();
+    sc->device    = device;
+    sc->bytes     = 0;
+    sc->n_ev      = 0;
+    sc->ws        = nullptr;
+    sc->ws_bytes  = 0;
+    memset(&sc->dev, 0, sizeof sc->dev);
+    SceneDev& S = sc->dev;
+
+#define UP(call)                      \
+    if ((rc = (call)) != RTX_OK) {    \
+        rtx_scene_destroy(sc);        \
+        return rc;                    \
+    }
+    {
+        std::vector<uint2> nodes(d->n_nodes);
+        for (uint32_t i = 0; i < d->n_nodes; i++) nodes[i] = make_uint2(d->node_w0[i], d->node_w1[i]);
+        UP(upload(sc, nodes.data(), nodes.size(), &S.nodes));
+    }
+    UP(upload(sc, d->leaf_ref, d->n_refs, &S.leaf_ref));
+    {
+        const size_t        T = d->n_tris;
+        std::vector<float4> hot(3 * T), cold(4 * T);
+        for (size_t i = 0; i < T; i++) {
+            float p[9], nn[9], uv[6];
+            for (int c = 0; c < 9; c++) p[c] = d->tri_pos[c * T + i], nn[c] = d->tri_nrm[c * T + i];
+            for (int c = 0; c < 6; c++) uv[c] = d->tri_uv[c * T + i];
+            // edge1 = v1 - v0, edge2 = v2 - v0 (surfaces.c:137-138), one binary32 subtraction each
+            float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+            float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+            hot[3 * i + 0]  = make_float4(p[0], p[1], p[2], e1x);
+            hot[3 * i + 1]  = make_float4(e1y, e1z, e2x, e2y);
+            hot[3 * i + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+            uint32_t mat    = d->tri_mat[i];
+            float    matf;
+            memcpy(&matf, &mat, 4);
+            cold[4 * i + 0] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+            cold[4 * i + 1] = make_float4(nn[4], nn[5], nn[6], nn[7]);
+            cold[4 * i + 2] = make_float4(nn[8], uv[0], uv[1], uv[2]);
+            cold[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], matf);
+        }
+        UP(upload(sc, hot.data(), hot.size(), &S.tri));
+        UP(upload(sc, cold.data(), cold.size(), &S.tri_shade));
+        UP(upload(sc, d->tri_obj, T, &S.tri_obj));
+    }
+    {
+        const size_t          Sn = d->n_spheres;
+        std::vector<float4>   sp(Sn);
+        std::vector<uint32_t> sm(Sn);
+        for (size_t i = 0; i < Sn; i++) {
+            sp[i] = make_float4(d->sph[0 * Sn + i], d->sph[1 * Sn + i], d->sph[2 * Sn + i], d->sph[3 * Sn + i]);
+            sm[i] = d->sph_mat[i];
+        }
+        UP(upload(sc, sp.data(), Sn, &S.sph));
+        UP(upload(sc, sm.data(), Sn, &S.sph_mat));
+        UP(upload(sc, d->sph_obj, Sn, &S.sph_obj));
+    }
+    {
+        const size_t       P = d->n_planes;
+        std::vector<float> pl(8 * P);
+        for (size_t i = 0; i < P; i++) {
+            for (int c = 0; c < 6; c++) pl[8 * i + c] = d->plane[c * P + i];
+            uint32_t mat = d->plane_mat[i];
+            memcpy(&pl[8 * i + 6], &mat, 4);
+            pl[8 * i + 7] = 0.0f;
+        }
+        UP(upload(sc, pl.data(), pl.size(), &S.plane));
+    }
+    UP(upload(sc, d->materials, d->n_materials, &S.mats));
+    UP(upload(sc, d->textures, d->n_textures, &S.tex));
+    UP(upload(sc, d->tex_data, (size_t)d->tex_texels * 3, &S.tex_data));
+    {
+        const uint64_t* c = nullptr;
+        std::vector<uint64_t> zeros(16, 0);
+        UP(upload(sc, zeros.data(), zeros.size(), &c));
+        sc->d_counters = (uint64_t*)c;
+    }
+#undef UP
+    S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
+    S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root = d->root_index;
+    for (int i = 0; i < 6; i++) S.skybox_tex[i] = d->skybox_tex[i];
+    *out = sc;
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// path queues: SoA, `cap` dwords per component
+// ---------------------------------------------------------------------------------------------
+enum { Q_OX, Q_OY, Q_OZ, Q_DX, Q_DY, Q_DZ, Q_TR, Q_TG, Q_TB, Q_S0, Q_S1, Q_S2, Q_S3, Q_PID, Q_COMPONENTS };
+
+struct Queue {
+    float*   base;
+    uint64_t cap;
+    DEV float&    f(int c, uint64_t i) const { return base[(uint64_t)c * cap + i]; }
+    DEV uint32_t& u(int c, uint64_t i) const { return ((uint32_t*)base)[(uint64_t)c * cap + i]; }
+};
+
+struct Hits { // SoA: ref, t, u, v
+    uint32_t* base;
+    uint64_t  cap;
+};
+
+struct FrameGeom {
+    uint32_t width, height, spp;
+    uint32_t band_rows, band_rank, band_world; // band_rows == 0: every row
+    uint32_t sample_begin, n_samples;
+    uint64_t seed_lo, seed_hi;
+    uint32_t pixel_centres;
+};
+
+// k-th row assigned to this rank → image row
+DEV uint32_t assigned_row(const FrameGeom& g, uint32_t k)
+{
+    if (g.band_rows == 0) return k;
+    uint32_t j = k / g.band_rows, within = k % g.band_rows;
+    return (g.band_rank + j * g.band_world) * g.band_rows + within;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+// RenderPixel's sample set-up (renderer.c:100-104) + Camera_GetRay (camera.c:34-49) + Ray_Make
+DEV void camera_sample(const rtx_camera& cam, const FrameGeom& g, uint32_t xx, uint32_t yy, uint32_t s, Rng& rng, f3& o, f3& d)
+{
+    uint64_t pixel = (uint64_t)yy * g.width + xx;
+    rng_seed(rng, g.seed_lo ^ (pixel * g.spp + s), g.seed_hi);
+    float hf, vf;
+    if (g.pixel_centres) {
+        hf = ((float)xx + 0.5f) / (float)(g.width - 1);
+        vf = ((float)yy + 0.5f) / (float)(g.height - 1);
+    } else {
+        hf = ((float)xx + Random_Unilateral(rng)) / (float)(g.width - 1);
+        vf = ((float)yy + Random_Unilateral(rng)) / (float)(g.height - 1);
+    }
+    float rdx, rdy;
+    Random_InDisc(rng, cam.lens_radius, rdx, rdy);
+    f3 offset = mk3(hf * rdx, vf * rdy, 0);
+    f3 corg   = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    f3 blc    = mk3(cam.bottom_left[0], cam.bottom_left[1], cam.bottom_left[2]);
+    f3 hor    = mk3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    f3 ver    = mk3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    o         = vadd(corg, offset);
+    f3 dir    = vsub(vadd(blc, vadd(vmuls(hor, hf), vmuls(ver, vf))), vadd(corg, offset));
+    d         = vnorm(dir); // Ray_Make, ray.c:6
+}
+
+__global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uint64_t first_pixel, uint64_t n, Queue q)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t pl = first_pixel + i / g.n_samples; // index in this rank's pixel list
+    uint32_t s  = g.sample_begin + (uint32_t)(i % g.n_samples);
+    uint32_t xx = (uint32_t)(pl % g.width);
+    uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+    Rng      rng;
+    f3       o, d;
+    camera_sample(cam, g, xx, yy, s, rng, o, d);
+    q.f(Q_OX, i) = o.x, q.f(Q_OY, i) = o.y, q.f(Q_OZ, i) = o.z;
+    q.f(Q_DX, i) = d.x, q.f(Q_DY, i) = d.y, q.f(Q_DZ, i) = d.z;
+    q.f(Q_TR, i) = 1.0f, q.f(Q_TG, i) = 1.0f, q.f(Q_TB, i) = 1.0f;
+    q.u(Q_S0, i) = rng.s0, q.u(Q_S1, i) = rng.s1, q.u(Q_S2, i) = rng.s2, q.u(Q_S3, i) = rng.s3;
+    q.u(Q_PID, i) = (uint32_t)i;
+}
+
+DEV void add_visits(uint64_t* counters, const Visits& v)
+{
+    // wave reduction, one atomic per wave and counter
+    uint32_t a = v.inner, b = v.leaf, c = v.prim;
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+        c += __shfl_down(c, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&counters[0], (unsigned long long)a);
+        atomicAdd((unsigned long long*)&counters[1], (unsigned long long)b);
+        atomicAdd((unsigned long long*)&counters[2], (unsigned long long)c);
+    }
+}
+
+// closest hit for a dense queue of unit-direction rays (6 SoA components at rays + c*stride)
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_trace(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+                                              uint32_t* __restrict__ hits, uint64_t hstride, uint64_t* counters)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Visits   vis = {0, 0, 0};
+    if (i < n) {
+        f3       o = mk3(rays[0 * stride + i], rays[1 * stride + i], rays[2 * stride + i]);
+        f3       d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        RayD     r = ray_from_unit(o, d);
+        uint32_t ref;
+        float    t, u, v;
+        closest_hit<COUNT>(S, r, ref, t, u, v, vis);
+        hits[0 * hstride + i] = ref;
+        hits[1 * hstride + i] = __float_as_uint(t);
+        hits[2 * hstride + i] = __float_as_uint(u);
+        hits[3 * hstride + i] = __float_as_uint(v);
+    }
+    if (COUNT) add_visits(counters, vis);
+}
+
+// Material_Bounce for every ray of the queue + compaction of the survivors into `qout`
+__global__ __launch_bounds__(256) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
+                                                unsigned long long* out_count, unsigned long long* shaded_count,
+                                                float* __restrict__ result, uint64_t rcap, int last)
+{
+    __shared__ uint32_t s_wave_cnt[4];
+    __shared__ uint64_t s_base;
+    uint64_t  i     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool      alive = false;
+    f3        o2 = mk3(0, 0, 0), d2 = mk3(0, 0, 1), T = mk3(0, 0, 0);
+    Rng       rng = {0, 0, 0, 0};
+    uint32_t  pid = 0;
+    bool      shaded = false;
+    if (i < n) {
+        f3 o = mk3(qin.f(Q_OX, i), qin.f(Q_OY, i), qin.f(Q_OZ, i));
+        f3 d = mk3(qin.f(Q_DX, i), qin.f(Q_DY, i), qin.f(Q_DZ, i));
+        T    = mk3(qin.f(Q_TR, i), qin.f(Q_TG, i), qin.f(Q_TB, i));
+        pid  = qin.u(Q_PID, i);
+        uint32_t ref = hits.base[0 * hits.cap + i];
+        if (ref == HIT_MISS) { // Scene_Get_SkyColor(ray->dir), renderer.c:75
+            f3 sky = Skybox_ColorAt(S, d);
+            f3 L   = vmulc(T, sky);
+            result[0 * rcap + pid] = L.x, result[1 * rcap + pid] = L.y, result[2 * rcap + pid] = L.z;
+        } else {
+            float t = __uint_as_float(hits.base[1 * hits.cap + i]);
+            float u = __uint_as_float(hits.base[2 * hits.cap + i]);
+            float v = __uint_as_float(hits.base[3 * hits.cap + i]);
+            rng     = Rng{qin.u(Q_S0, i), qin.u(Q_S1, i), qin.u(Q_S2, i), qin.u(Q_S3, i)};
+            HitD h  = make_hitinfo(S, o, d, ref, t, u, v);
+            f3   surf, emit, dout;
+            bool cont = Material_Bounce(S, S.mats[h.mat], d, h, rng, surf, emit, dout);
+            shaded    = true;
+            if (cont) {
+                // emitted is black for every continuing material, so E + S*L(next) == S*L(next)
+                T     = vmulc(T, surf);
+                o2    = h.pos;
+                d2    = vnorm(dout); // Ray_Make
+                alive = !last;
+                if (last) {
+                    // depth exhausted: RayColor(depth 0) is black (renderer.c:56-58) and the path returns
+                    // surface * black — zero, or NaN where a lobe produced an inf/NaN surface colour; the
+                    // reference's pixels carry those NaNs, so they are reproduced rather than dropped
+                    f3 L = vmulc(T, mk3(0.0f, 0.0f, 0.0f));
+                    result[0 * rcap + pid] = L.x, result[1 * rcap + pid] = L.y, result[2 * rcap + pid] = L.z;
+                }
+            } else {
+                f3 L = vmulc(T, emit);
+                result[0 * rcap + pid] = L.x, result[1 * rcap + pid] = L.y, result[2 * rcap + pid] = L.z;
+            }
+        }
+    }
+    // ---- compaction: ballot within the wave, one atomic per block ----
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(alive);
+    const uint32_t wcnt = __popcll(mask);
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long smask = __ballot(shaded);
+    if (lane == 0) s_wave_cnt[wave] = wcnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_base         = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
+    }
+    if (lane == 0 && smask) atomicAdd(shaded_count, (unsigned long long)__popcll(smask));
+    __syncthreads();
+    if (alive) {
+        uint64_t pos = s_base + rank;
+        for (uint32_t w = 0; w < wave; w++) pos += s_wave_cnt[w];
+        qout.f(Q_OX, pos) = o2.x, qout.f(Q_OY, pos) = o2.y, qout.f(Q_OZ, pos) = o2.z;
+        qout.f(Q_DX, pos) = d2.x, qout.f(Q_DY, pos) = d2.y, qout.f(Q_DZ, pos) = d2.z;
+        qout.f(Q_TR, pos) = T.x, qout.f(Q_TG, pos) = T.y, qout.f(Q_TB, pos) = T.z;
+        qout.u(Q_S0, pos) = rng.s0, qout.u(Q_S1, pos) = rng.s1, qout.u(Q_S2, pos) = rng.s2, qout.u(Q_S3, pos) = rng.s3;
+        qout.u(Q_PID, pos) = pid;
+    }
+}
+
+// RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel
+__global__ __launch_bounds__(256) void k_resolve_slab(const float* __restrict__ result, uint64_t rcap, FrameGeom g,
+                                                       uint64_t first_pixel, uint64_t n_pixels, float* __restrict__ accum)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    uint64_t pl = first_pixel + p;
+    uint32_t xx = (uint32_t)(pl % g.width);
+    uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+    f3       cum = mk3(0, 0, 0);
+    uint64_t b   = p * g.n_samples;
+    for (uint32_t s = 0; s < g.n_samples; s++) {
+        cum = vadd(cum, mk3(result[0 * rcap + b + s], result[1 * rcap + b + s], result[2 * rcap + b + s]));
+    }
+    uint64_t o = ((uint64_t)yy * g.width + xx) * 3;
+    accum[o + 0] += cum.x;
+    accum[o + 1] += cum.y;
+    accum[o + 2] += cum.z;
+}
+
+DEV uint8_t LinearTosRGB(float channel) // src/gfx/color.c:18-29
+{
+    float linear = clampf_(channel, 0.0f, 1.0f);
+    if (linear < 0.0031308f) {
+        float srgb = linear * 12.92f;
+        return (uint8_t)(255.0f * srgb);
+    } else {
+        float srgb = 1.055f * powf(linear, 1.0f / 2.4f) - 0.055f;
+        return (uint8_t)(255.0f * srgb);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ accum, uint64_t n_pixels, float inv_spp, uint8_t* __restrict__ bgr)
+{
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    // avg = vdiv(cum, spp) = cum * (1.0f/spp) (renderer.c:109, vec.c:198); RGB{b,g,r} (color.h:19-23)
+    bgr[3 * p + 0] = LinearTosRGB(inv_spp * accum[3 * p + 2]);
+    bgr[3 * p + 1] = LinearTosRGB(inv_spp * accum[3 * p + 1]);
+    bgr[3 * p + 2] = LinearTosRGB(inv_spp * accum[3 * p + 0]);
+}
+
+// ---- parity-seam kernels (small batches) ----
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_trace_full(SceneDev S, const float* __restrict__ o_xyz, const float* __restrict__ d_xyz, uint64_t n,
+                                                   uint32_t* prim_id, float* t_out, float* pos, float* nrm, float* uv, uint8_t* front,
+                                                   uint64_t* counters, int unit_dir)
+{
+    uint64_t i   = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Visits   vis = {0, 0, 0};
+    if (i < n) {
+        f3       o = mk3(o_xyz[3 * i], o_xyz[3 * i + 1], o_xyz[3 * i + 2]);
+        f3       d = mk3(d_xyz[3 * i], d_xyz[3 * i + 1], d_xyz[3 * i + 2]);
+        if (!unit_dir) d = vnorm(d); // Ray_Make
+        RayD     r = ray_from_unit(o, d);
+        uint32_t ref;
+        float    t, u, v;
+        closest_hit<COUNT>(S, r, ref, t, u, v, vis);
+        if (prim_id) prim_id[i] = hit_prim_id(S, ref);
+        HitD h;
+        if (ref != HIT_MISS) {
+            h = make_hitinfo(S, o, d, ref, t, u, v);
+        } else {
+            h.pos = mk3(0, 0, 0), h.n = mk3(0, 0, 0), h.u = 0, h.v = 0, h.front = false, h.mat = 0;
+            t = 0.0f;
+        }
+        if (t_out) t_out[i] = t;
+        if (pos) pos[3 * i] = h.pos.x, pos[3 * i + 1] = h.pos.y, pos[3 * i + 2] = h.pos.z;
+        if (nrm) nrm[3 * i] = h.n.x, nrm[3 * i + 1] = h.n.y, nrm[3 * i + 2] = h.n.z;
+        if (uv) uv[2 * i] = h.u, uv[2 * i + 1] = h.v;
+        if (front) front[i] = h.front ? 1 : 0;
+    }
+    if (COUNT) add_visits(counters, vis);
+}
+
+__global__ void k_camera_rays(rtx_camera cam, FrameGeom g, uint64_t n, const uint32_t* pixel_index, const uint32_t* sample, float* o_xyz,
+                              float* d_xyz, uint32_t* state)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t xx = pixel_index[i] % g.width, yy = pixel_index[i] / g.width;
+    Rng      rng;
+    f3       o, d;
+    camera_sample(cam, g, xx, yy, sample[i], rng, o, d);
+    o_xyz[3 * i] = o.x, o_xyz[3 * i + 1] = o.y, o_xyz[3 * i + 2] = o.z;
+    d_xyz[3 * i] = d.x, d_xyz[3 * i + 1] = d.y, d_xyz[3 * i + 2] = d.z;
+    if (state) state[4 * i] = rng.s0, state[4 * i + 1] = rng.s1, state[4 * i + 2] = rng.s2, state[4 * i + 3] = rng.s3;
+}
+
+__global__ void k_rng(uint64_t lo, uint64_t hi, uint64_t n, float* out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    Rng rng;
+    rng_seed(rng, lo, hi);
+    for (uint64_t i = 0; i < n; i++) out[i] = Random_Unilateral(rng);
+}
+
+__global__ void k_bounce(SceneDev S, uint32_t mat, uint64_t n, const float* dir, const float* pos, const float* nrm, const float* uv,
+                         const uint8_t* front, uint32_t* state, float* surf, float* emit, float* oo, float* od, uint8_t* cont)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    HitD h;
+    h.pos   = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    h.n     = mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    h.u     = uv[2 * i];
+    h.v     = uv[2 * i + 1];
+    h.front = front[i] != 0;
+    h.mat   = mat;
+    Rng rng = {state[4 * i], state[4 * i + 1], state[4 * i + 2], state[4 * i + 3]};
+    f3  s, e, dout;
+    bool c = Material_Bounce(S, S.mats[mat], mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), h, rng, s, e, dout);
+    f3  dn = vnorm(dout); // Ray_Make(hit->position, dir)
+    surf[3 * i] = s.x, surf[3 * i + 1] = s.y, surf[3 * i + 2] = s.z;
+    emit[3 * i] = e.x, emit[3 * i + 1] = e.y, emit[3 * i + 2] = e.z;
+    oo[3 * i] = h.pos.x, oo[3 * i + 1] = h.pos.y, oo[3 * i + 2] = h.pos.z;
+    od[3 * i] = dn.x, od[3 * i + 1] = dn.y, od[3 * i + 2] = dn.z;
+    cont[i]   = c ? 1 : 0;
+    state[4 * i] = rng.s0, state[4 * i + 1] = rng.s1, state[4 * i + 2] = rng.s2, state[4 * i + 3] = rng.s3;
+}
+
+__global__ void k_sky(SceneDev S, uint64_t n, const float* dir, float* rgb)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 c = Skybox_ColorAt(S, mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+struct DevBuf { // RAII device buffer for the host-pointer entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
+                        bool count, uint64_t* d_counters)
+{
+    if (n == 0) return RTX_OK;
+    if (n > (uint64_t)0x7FFFFFFF * 64) return fail(RTX_E_LIMIT, "too many rays for one launch");
+    unsigned nb = blocks_for(n, 64);
+    if (count) {
+        hipLaunchKernelGGL(k_trace<true>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
+    } else {
+        hipLaunchKernelGGL(k_trace<false>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
+    }
+    HIPCHECK(hipGetLastError());
+    return RTX_OK;
+}
+
+extern "C" int rtx_trace_closest_device(rtx_scene* sc, size_t n, const float* d_rays, uint32_t* d_hits, void* stream, uint32_t flags,
+                                        uint64_t* d_visit_counters)
+{
+    if (!sc || (n && (!d_rays || !d_hits))) return fail(RTX_E_INVALID, "null argument");
+    bool count = (flags & RTX_RENDER_COUNT_VISITS) != 0;
+    if (count && !d_visit_counters) return fail(RTX_E_INVALID, "COUNT_VISITS needs a counter buffer (3 x u64)");
+    HIPCHECK(hipSetDevice(sc->device));
+    return launch_trace(sc, d_rays, n, n, d_hits, n, (hipStream_t)stream, count, d_visit_counters);
+}
+
+extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xyz, const float* dir_xyz, uint32_t* prim_id, float* t,
+                                 float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face, rtx_stats* stats, uint32_t flags)
+{
+    if (!sc || (n && (!origin_xyz || !dir_xyz))) return fail(RTX_E_INVALID, "null argument");
+    if (stats) memset(stats, 0, sizeof *stats);
+    HIPCHECK(hipSetDevice(sc->device));
+    bool         count = (flags & RTX_RENDER_COUNT_VISITS) != 0;
+    const int    unit_dir = (flags & RTX_TRACE_UNIT_DIR) ? 1 : 0;
+    const size_t CH    = 1u << 22;
+    DevBuf       bo, bd, bid, bt, bp, bn, buv, bf;
+    size_t       m = std::min(n, CH);
+    HIPCHECK(bo.alloc(m * 12));
+    HIPCHECK(bd.alloc(m * 12));
+    HIPCHECK(bid.alloc(m * 4));
+    HIPCHECK(bt.alloc(m * 4));
+    HIPCHECK(bp.alloc(m * 12));
+    HIPCHECK(bn.alloc(m * 12));
+    HIPCHECK(buv.alloc(m * 8));
+    HIPCHECK(bf.alloc(m));
+    HIPCHECK(hipMemset(sc->d_counters, 0, 16 * sizeof(uint64_t)));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    double ms_total = 0.0;
+    for (size_t off = 0; off < n; off += CH) {
+        size_t k = std::min(CH, n - off);
+        HIPCHECK(hipMemcpy(bo.p, origin_xyz + 3 * off, k * 12, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(bd.p, dir_xyz + 3 * off, k * 12, hipMemcpyHostToDevice));
+        HIPCHECK(hipEventRecord(e0, 0));
+        if (count) {
+            hipLaunchKernelGGL(k_trace_full<true>, dim3(blocks_for(k, 64)), dim3(64), 0, 0, sc->dev, bo.as<float>(), bd.as<float>(), (uint64_t)k,
+                               bid.as<uint32_t>(), bt.as<float>(), bp.as<float>(), bn.as<float>(), buv.as<float>(), bf.as<uint8_t>(), sc->d_counters, unit_dir);
+        } else {
+            hipLaunchKernelGGL(k_trace_full<false>, dim3(blocks_for(k, 64)), dim3(64), 0, 0, sc->dev, bo.as<float>(), bd.as<float>(), (uint64_t)k,
+                               bid.as<uint32_t>(), bt.as<float>(), bp.as<float>(), bn.as<float>(), buv.as<float>(), bf.as<uint8_t>(), sc->d_counters, unit_dir);
+        }
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipEventRecord(e1, 0));
+        HIPCHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms_total += ms;
+        if (prim_id) HIPCHECK(hipMemcpy(prim_id + off, bid.p, k * 4, hipMemcpyDeviceToHost));
+        if (t) HIPCHECK(hipMemcpy(t + off, bt.p, k * 4, hipMemcpyDeviceToHost));
+        if (position_xyz) HIPCHECK(hipMemcpy(position_xyz + 3 * off, bp.p, k * 12, hipMemcpyDeviceToHost));
+        if (normal_xyz) HIPCHECK(hipMemcpy(normal_xyz + 3 * off, bn.p, k * 12, hipMemcpyDeviceToHost));
+        if (uv) HIPCHECK(hipMemcpy(uv + 2 * off, buv.p, k * 8, hipMemcpyDeviceToHost));
+        if (front_face) HIPCHECK(hipMemcpy(front_face + off, bf.p, k, hipMemcpyDeviceToHost));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stats) {
+        stats->rays_total       = n;
+        stats->rays_at_depth[0] = n;
+        stats->ms_trace = stats->ms_total = ms_total;
+        stats->trace_launches             = (uint32_t)((n + CH - 1) / CH);
+        if (count) {
+            uint64_t c[3];
+            HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+            stats->visits_inner = c[0], stats->visits_leaf = c[1], stats->visits_prim = c[2];
+        }
+    }
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame rendering
+// ---------------------------------------------------------------------------------------------
+static int check_params(const rtx_render_params* p, FrameGeom* g, uint32_t* rows_out)
+{
+    if (!p) return fail(RTX_E_INVALID, "null render params");
+    if (p->width < 2 || p->height < 2) return fail(RTX_E_INVALID, "image must be at least 2x2 (u = x/(w-1), renderer.c:101)");
+    if (p->width > 65536 || p->height > 65536) return fail(RTX_E_LIMIT, "image larger than 65536 per side");
+    if (p->spp == 0) return fail(RTX_E_INVALID, "spp must be positive");
+    if (p->max_depth > RTX_MAX_DEPTH) return fail(RTX_E_LIMIT, "max_depth above %d", RTX_MAX_DEPTH);
+    uint32_t sb = p->sample_begin, se = p->sample_end;
+    if (sb == 0 && se == 0) se = p->spp;
+    if (sb >= se || se > p->spp) return fail(RTX_E_INVALID, "bad sample range [%u,%u) for spp %u", sb, se, p->spp);
+    if (p->band_rows && (p->band_world == 0 || p->band_rank >= p->band_world)) return fail(RTX_E_INVALID, "bad band partition");
+    g->width = p->width, g->height = p->height, g->spp = p->spp;
+    g->band_rows  = (p->band_rows && p->band_world > 1) ? p->band_rows : 0;
+    g->band_rank  = p->band_rank;
+    g->band_world = p->band_world ? p->band_world : 1;
+    g->sample_begin = sb, g->n_samples = se - sb;
+    g->seed_lo = p->seed_lo, g->seed_hi = p->seed_hi;
+    g->pixel_centres = (p->flags & RTX_RENDER_PIXEL_CENTRES) ? 1 : 0;
+    uint32_t rows = 0;
+    if (g->band_rows == 0) {
+        rows = p->height;
+    } else {
+        uint32_t nb = (p->height + g->band_rows - 1) / g->band_rows;
+        for (uint32_t b = g->band_rank; b < nb; b += g->band_world) rows += std::min(g->band_rows, p->height - b * g->band_rows);
+    }
+    *rows_out = rows;
+    return RTX_OK;
+}
+
+static int get_event(rtx_scene* sc, int i, hipEvent_t* ev)
+{
+    while (sc->n_ev <= i) {
+        if (sc->n_ev >= (int)(sizeof sc->ev / sizeof sc->ev[0])) return fail(RTX_E_LIMIT, "too many timed launches in one call");
+        HIPCHECK(hipEventCreate(&sc->ev[sc->n_ev]));
+        sc->n_ev++;
+    }
+    *ev = sc->ev[i];
+    return RTX_OK;
+}
+
+extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, float* d_accum, void* stream, rtx_stats* stats)
+{
+    if (!sc || !cam || !d_accum) return fail(RTX_E_INVALID, "null argument");
+    FrameGeom g;
+    uint32_t  rows = 0;
+    int       rc   = check_params(p, &g, &rows);
+    if (rc != RTX_OK) return rc;
+    HIPCHECK(hipSetDevice(sc->device));
+    hipStream_t st = (hipStream_t)stream;
+    rtx_stats   local;
+    memset(&local, 0, sizeof local);
+    const bool count = (p->flags & RTX_RENDER_COUNT_VISITS) != 0;
+
+    const uint64_t n_pixels = (uint64_t)rows * g.width;
+    const uint64_t total    = n_pixels * g.n_samples;
+    if (total == 0 || p->max_depth == 0) { // depth 0 → every RayColor is black: accum stays as is
+        if (stats) *stats = local;
+        return RTX_OK;
+    }
+    // slab sizing: whole pixels, at most `budget` paths in flight
+    uint64_t budget = p->max_paths_in_flight ? p->max_paths_in_flight : (32ull << 20);
+    if (budget > 0xFFFFFF00ull) budget = 0xFFFFFF00ull; // path ids are u32
+    uint64_t px_per_slab = std::max<uint64_t>(1, budget / g.n_samples);
+    px_per_slab          = std::min(px_per_slab, n_pixels);
+    const uint64_t cap   = px_per_slab * g.n_samples;
+    if (cap > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "spp too large for one slab");
+
+    const uint64_t qbytes = cap * Q_COMPONENTS * 4;
+    char*          ws     = nullptr;
+    if ((rc = workspace(sc, 2 * qbytes + cap * 16 + cap * 12, &ws)) != RTX_OK) return rc;
+    Queue  q[2]   = {{(float*)ws, cap}, {(float*)(ws + qbytes), cap}};
+    Hits   hits   = {(uint32_t*)(ws + 2 * qbytes), cap};
+    float* result = (float*)(ws + 2 * qbytes + cap * 16);
+
+    unsigned long long* d_cnt    = (unsigned long long*)&sc->d_counters[3];
+    unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
+    HIPCHECK(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint64_t), st));
+
+    int        nev = 0;
+    hipEvent_t evA, evB;
+    if ((rc = get_event(sc, nev++, &evA)) != RTX_OK) return rc;
+    if ((rc = get_event(sc, nev++, &evB)) != RTX_OK) return rc;
+    HIPCHECK(hipEventRecord(evA, st));
+    struct Span { int a, b, kind; };
+    std::vector<Span> spans;
+    auto timed = [&](int kind, auto&& launch) -> int {
+        hipEvent_t a, b;
+        int        ia = nev, ib = nev + 1, r;
+        if ((r = get_event(sc, nev++, &a)) != RTX_OK) return r;
+        if ((r = get_event(sc, nev++, &b)) != RTX_OK) return r;
+        HIPCHECK(hipEventRecord(a, st));
+        launch();
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipEventRecord(b, st));
+        spans.push_back({ia, ib, kind});
+        return RTX_OK;
+    };
+
+    for (uint64_t px0 = 0; px0 < n_pixels; px0 += px_per_slab) {
+        const uint64_t npx = std::min(px_per_slab, n_pixels - px0);
+        uint64_t       n   = npx * g.n_samples;
+        local.passes++;
+        local.camera_paths += n;
+        HIPCHECK(hipMemsetAsync(result, 0, cap * 12, st));
+        rc = timed(0, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, st, *cam, g, px0, n, q[0]); });
+        if (rc != RTX_OK) return rc;
+        int cur = 0;
+        for (uint32_t depth = 0; depth < p->max_depth && n > 0; depth++) {
+            local.rays_at_depth[depth] += n;
+            local.rays_total += n;
+            rc = timed(1, [&] { (void)launch_trace(sc, q[cur].base, cap, n, hits.base, cap, st, count, sc->d_counters); });
+            if (rc != RTX_OK) return rc;
+            local.trace_launches++;
+            HIPCHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+            const int last = depth + 1 == p->max_depth;
+            rc = timed(2, [&] {
+                hipLaunchKernelGGL(k_shade, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc->dev, q[cur], hits, n, q[cur ^ 1], d_cnt, d_shaded,
+                                   result, cap, last);
+            });
+            if (rc != RTX_OK) return rc;
+            unsigned long long alive = 0;
+            if (!last) {
+                HIPCHECK(hipMemcpyAsync(&alive, d_cnt, sizeof alive, hipMemcpyDeviceToHost, st));
+                HIPCHECK(hipStreamSynchronize(st));
+            }
+            n   = alive;
+            cur ^= 1;
+        }
+        rc = timed(3, [&] {
+            hipLaunchKernelGGL(k_resolve_slab, dim3(blocks_for(npx, 256)), dim3(256), 0, st, result, cap, g, px0, npx, d_accum);
+        });
+        if (rc != RTX_OK) return rc;
+    }
+    HIPCHECK(hipEventRecord(evB, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, evA, evB));
+    local.ms_total = ms;
+    for (const Span& s : spans) {
+        HIPCHECK(hipEventElapsedTime(&ms, sc->ev[s.a], sc->ev[s.b]));
+        (s.kind == 0 ? local.ms_raygen : s.kind == 1 ? local.ms_trace : s.kind == 2 ? local.ms_shade : local.ms_resolve) += ms;
+    }
+    uint64_t c[5];
+    HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2];
+    local.hits_shaded  = c[4];
+    if (stats) *stats = local;
+    return RTX_OK;
+}
+
+extern "C" int rtx_resolve_device(rtx_scene* sc, const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_bgr, void* stream)
+{
+    if (!sc || !d_accum || !d_bgr || !spp) return fail(RTX_E_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(sc->device));
+    uint64_t n = (uint64_t)width * height;
+    hipLaunchKernelGGL(k_tonemap, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_accum, n, 1.0f / (float)spp, d_bgr);
+    HIPCHECK(hipGetLastError());
+    return RTX_OK;
+}
+
+extern "C" int rtx_render(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, uint8_t* bgr_out, float* accum_out, rtx_stats* stats)
+{
+    if (!sc || !cam || !p) return fail(RTX_E_INVALID, "null argument");
+    HIPCHECK(hipSetDevice(sc->device));
+    const uint64_t npx = (uint64_t)p->width * p->height;
+    DevBuf         bacc, bbgr;
+    HIPCHECK(bacc.alloc(npx * 12));
+    HIPCHECK(bbgr.alloc(npx * 3));
+    HIPCHECK(hipMemset(bacc.p, 0, npx * 12));
+    int rc = rtx_render_device(sc, cam, p, bacc.as<float>(), nullptr, stats);
+    if (rc != RTX_OK) return rc;
+    if (bgr_out) {
+        rc = rtx_resolve_device(sc, bacc.as<float>(), p->width, p->height, p->spp, bbgr.as<uint8_t>(), nullptr);
+        if (rc != RTX_OK) return rc;
+        HIPCHECK(hipMemcpy(bgr_out, bbgr.p, npx * 3, hipMemcpyDeviceToHost));
+    }
+    if (accum_out) {
+        // rows not assigned to this call stay untouched in the caller's buffer
+        FrameGeom g;
+        uint32_t  rows;
+        check_params(p, &g, &rows);
+        if (g.band_rows == 0) {
+            HIPCHECK(hipMemcpy(accum_out, bacc.p, npx * 12, hipMemcpyDeviceToHost));
+        } else {
+            uint32_t nb = (p->height + g.band_rows - 1) / g.band_rows;
+            for (uint32_t b = g.band_rank; b < nb; b += g.band_world) {
+                uint64_t r0 = (uint64_t)b * g.band_rows, nr = std::min<uint64_t>(g.band_rows, p->height - r0);
+                HIPCHECK(hipMemcpy(accum_out + r0 * p->width * 3, bacc.as<float>() + r0 * p->width * 3, nr * p->width * 12, hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-level parity seams
+// ---------------------------------------------------------------------------------------------
+extern "C" int rtx_camera_rays(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, size_t n, const uint32_t* pixel_index,
+                               const uint32_t* sample, float* origin_xyz, float* dir_xyz, uint32_t* rng_state4)
+{
+    if (!sc || !cam || (n && (!pixel_index || !sample || !origin_xyz || !dir_xyz))) return fail(RTX_E_INVALID, "null argument");
+    FrameGeom g;
+    uint32_t  rows;
+    int       rc = check_params(p, &g, &rows);
+    if (rc != RTX_OK) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (pixel_index[i] >= (uint64_t)p->width * p->height || sample[i] >= p->spp) return fail(RTX_E_INVALID, "path %zu out of range", i);
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(sc->device));
+    DevBuf bp, bs, bo, bd, bst;
+    HIPCHECK(bp.alloc(n * 4));
+    HIPCHECK(bs.alloc(n * 4));
+    HIPCHECK(bo.alloc(n * 12));
+    HIPCHECK(bd.alloc(n * 12));
+    HIPCHECK(bst.alloc(n * 16));
+    HIPCHECK(hipMemcpy(bp.p, pixel_index, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bs.p, sample, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocks_for(n, 64)), dim3(64), 0, 0, *cam, g, (uint64_t)n, bp.as<uint32_t>(), bs.as<uint32_t>(), bo.as<float>(),
+                       bd.as<float>(), bst.as<uint32_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(origin_xyz, bo.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(dir_xyz, bd.p, n * 12, hipMemcpyDeviceToHost));
+    if (rng_state4) HIPCHECK(hipMemcpy(rng_state4, bst.p, n * 16, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" int rtx_rng_unilateral(rtx_scene* sc, uint64_t seed_lo, uint64_t seed_hi, size_t n, float* out)
+{
+    if (!sc || (n && !out)) return fail(RTX_E_INVALID, "null argument");
+    if (n > (1u << 20)) return fail(RTX_E_LIMIT, "at most 2^20 draws");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(sc->device));
+    DevBuf b;
+    HIPCHECK(b.alloc(n * 4));
+    hipLaunchKernelGGL(k_rng, dim3(1), dim3(64), 0, 0, seed_lo, seed_hi, (uint64_t)n, b.as<float>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(out, b.p, n * 4, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" int rtx_material_bounce(rtx_scene* sc, uint32_t mat_index, size_t n, const float* ray_dir_xyz, const float* hit_position_xyz,
+                                   const float* hit_normal_xyz, const float* hit_uv, const uint8_t* front_face, uint32_t* rng_state4,
+                                   float* surface_rgb, float* emitted_rgb, float* out_origin_xyz, float* out_dir_xyz, uint8_t* cont)
+{
+    if (!sc || !ray_dir_xyz || !hit_position_xyz || !hit_normal_xyz || !hit_uv || !front_face || !rng_state4 || !surface_rgb || !emitted_rgb
+        || !out_origin_xyz || !out_dir_xyz || !cont)
+        return fail(RTX_E_INVALID, "null argument");
+    if (mat_index >= sc->dev.n_materials) return fail(RTX_E_INVALID, "material index out of range");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(sc->device));
+    DevBuf bdir, bpos, bn, buv, bf, bst, bs, be, boo, bod, bc;
+    HIPCHECK(bdir.alloc(n * 12));
+    HIPCHECK(bpos.alloc(n * 12));
+    HIPCHECK(bn.alloc(n * 12));
+    HIPCHECK(buv.alloc(n * 8));
+    HIPCHECK(bf.alloc(n));
+    HIPCHECK(bst.alloc(n * 16));
+    HIPCHECK(bs.alloc(n * 12));
+    HIPCHECK(be.alloc(n * 12));
+    HIPCHECK(boo.alloc(n * 12));
+    HIPCHECK(bod.alloc(n * 12));
+    HIPCHECK(bc.alloc(n));
+    HIPCHECK(hipMemcpy(bdir.p, ray_dir_xyz, n * 12, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bpos.p, hit_position_xyz, n * 12, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bn.p, hit_normal_xyz, n * 12, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(buv.p, hit_uv, n * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bf.p, front_face, n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(bst.p, rng_state4, n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bounce, dim3(blocks_for(n, 64)), dim3(64), 0, 0, sc->dev, mat_index, (uint64_t)n, bdir.as<float>(), bpos.as<float>(),
+                       bn.as<float>(), buv.as<float>(), bf.as<uint8_t>(), bst.as<uint32_t>(), bs.as<float>(), be.as<float>(), boo.as<float>(),
+                       bod.as<float>(), bc.as<uint8_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(surface_rgb, bs.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(emitted_rgb, be.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(out_origin_xyz, boo.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(out_dir_xyz, bod.p, n * 12, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(cont, bc.p, n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(rng_state4, bst.p, n * 16, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" int rtx_skybox_color(rtx_scene* sc, size_t n, const float* dir_xyz, float* rgb)
+{
+    if (!sc || (n && (!dir_xyz || !rgb))) return fail(RTX_E_INVALID, "null argument");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(sc->device));
+    DevBuf bd, bc;
+    HIPCHECK(bd.alloc(n * 12));
+    HIPCHECK(bc.alloc(n * 12));
+    HIPCHECK(hipMemcpy(bd.p, dir_xyz, n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sky, dim3(blocks_for(n, 64)), dim3(64), 0, 0, sc->dev, (uint64_t)n, bd.as<float>(), bc.as<float>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(rgb, bc.p, n * 12, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}

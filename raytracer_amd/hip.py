@@ -1,0 +1,203 @@
+"""ctypes binding of librt_hip.so (the C ABI of include/rtx.h) with numpy-friendly wrappers.
+
+There is no fallback: if the library is missing, or no HIP device is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .host import (LIB_DIR, rtx_camera, rtx_render_params, rtx_scene_desc, rtx_stats)
+
+RTX_RENDER_COUNT_VISITS = 1
+RTX_RENDER_PIXEL_CENTRES = 2
+RTX_TRACE_UNIT_DIR = 4
+RTX_ID_MISS = 0xFFFFFFFF
+RTX_ID_UNBOUNDED = 0x80000000
+
+EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
+           "rtx_scene_device_bytes", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
+           "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
+           "rtx_skybox_color"]
+
+_lib = None
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rtx error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(LIB_DIR, "librt_hip.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: the HIP extension was not built (python -m raytracer_amd.build)")
+    L = C.CDLL(path)
+    vp, u32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("rtx_abi_version", C.c_int)
+    sig("rtx_last_error", C.c_char_p)
+    sig("rtx_device_count", C.c_int, C.POINTER(C.c_int))
+    sig("rtx_scene_create", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.POINTER(vp))
+    sig("rtx_scene_destroy", C.c_int, vp)
+    sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
+    sig("rtx_trace_closest", C.c_int, vp, C.c_size_t, f32p, f32p, u32p, f32p, f32p, f32p, f32p, u8p,
+        C.POINTER(rtx_stats), C.c_uint32)
+    sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
+    sig("rtx_render", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), u8p, f32p,
+        C.POINTER(rtx_stats))
+    sig("rtx_render_device", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), vp, vp,
+        C.POINTER(rtx_stats))
+    sig("rtx_resolve_device", C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp)
+    sig("rtx_camera_rays", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
+        f32p, f32p, u32p)
+    sig("rtx_rng_unilateral", C.c_int, vp, C.c_uint64, C.c_uint64, C.c_size_t, f32p)
+    sig("rtx_material_bounce", C.c_int, vp, C.c_uint32, C.c_size_t, f32p, f32p, f32p, f32p, u8p, u32p, f32p, f32p,
+        f32p, f32p, u8p)
+    sig("rtx_skybox_color", C.c_int, vp, C.c_size_t, f32p, f32p)
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtxError(rc, lib().rtx_last_error().decode(errors="replace"))
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().rtx_device_count(C.byref(n)))
+    return n.value
+
+
+def stats_dict(st: rtx_stats) -> dict:
+    d = {n: getattr(st, n) for n, _ in st._fields_ if n != "rays_at_depth"}
+    d["rays_at_depth"] = [int(x) for x in st.rays_at_depth if x]
+    return d
+
+
+def make_params(width, height, spp, max_depth, seed=(1, 2), sample_range=None, band=None, flags=0,
+                max_paths_in_flight=0) -> rtx_render_params:
+    p = rtx_render_params()
+    p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
+    p.seed_lo, p.seed_hi = seed
+    if sample_range:
+        p.sample_begin, p.sample_end = sample_range
+    if band:
+        p.band_rows, p.band_rank, p.band_world = band
+    p.flags = flags
+    p.max_paths_in_flight = max_paths_in_flight
+    return p
+
+
+class DeviceScene:
+    """rtx_scene handle (one per scene and device)."""
+
+    def __init__(self, desc, device=0):
+        self.handle = C.c_void_p()
+        _check(lib().rtx_scene_create(desc, device, C.byref(self.handle)))
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib().rtx_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_bytes(self) -> int:
+        b = C.c_uint64(0)
+        _check(lib().rtx_scene_device_bytes(self.handle, C.byref(b)))
+        return b.value
+
+    # ---- Scene_ClosestHit, batched ----
+    def trace_closest(self, origin, direction, flags=0):
+        o = np.ascontiguousarray(origin, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
+        n = len(o)
+        out = dict(prim_id=np.empty(n, np.uint32), t=np.empty(n, np.float32), position=np.empty((n, 3), np.float32),
+                   normal=np.empty((n, 3), np.float32), uv=np.empty((n, 2), np.float32),
+                   front=np.empty(n, np.uint8))
+        st = rtx_stats()
+        _check(lib().rtx_trace_closest(self.handle, n, _p(o, C.c_float), _p(d, C.c_float), _p(out["prim_id"], C.c_uint32),
+                                       _p(out["t"], C.c_float), _p(out["position"], C.c_float),
+                                       _p(out["normal"], C.c_float), _p(out["uv"], C.c_float),
+                                       _p(out["front"], C.c_uint8), C.byref(st), flags))
+        out["stats"] = stats_dict(st)
+        return out
+
+    # ---- Render_Start equivalent, blocking ----
+    def render(self, cam, params, want_accum=True, want_bgr=True):
+        npx = params.width * params.height
+        bgr = np.zeros((params.height, params.width, 3), np.uint8) if want_bgr else None
+        acc = np.zeros((params.height, params.width, 3), np.float32) if want_accum else None
+        st = rtx_stats()
+        _check(lib().rtx_render(self.handle, C.byref(cam), C.byref(params), _p(bgr, C.c_uint8), _p(acc, C.c_float),
+                                C.byref(st)))
+        return bgr, acc, stats_dict(st)
+
+    def render_device(self, cam, params, d_accum_ptr, stream=0):
+        st = rtx_stats()
+        _check(lib().rtx_render_device(self.handle, C.byref(cam), C.byref(params), C.c_void_p(d_accum_ptr),
+                                       C.c_void_p(stream), C.byref(st)))
+        return stats_dict(st)
+
+    def resolve_device(self, d_accum_ptr, width, height, spp, d_bgr_ptr, stream=0):
+        _check(lib().rtx_resolve_device(self.handle, C.c_void_p(d_accum_ptr), width, height, spp,
+                                        C.c_void_p(d_bgr_ptr), C.c_void_p(stream)))
+
+    def trace_closest_device(self, n, d_rays_ptr, d_hits_ptr, stream=0, flags=0, d_counters_ptr=0):
+        _check(lib().rtx_trace_closest_device(self.handle, n, C.c_void_p(d_rays_ptr), C.c_void_p(d_hits_ptr),
+                                              C.c_void_p(stream), flags, C.c_void_p(d_counters_ptr)))
+
+    # ---- unit seams ----
+    def camera_rays(self, cam, params, pixel_index, sample):
+        pi = np.ascontiguousarray(pixel_index, np.uint32)
+        sa = np.ascontiguousarray(sample, np.uint32)
+        n = len(pi)
+        o, d, s = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty((n, 4), np.uint32)
+        _check(lib().rtx_camera_rays(self.handle, C.byref(cam), C.byref(params), n, _p(pi, C.c_uint32),
+                                     _p(sa, C.c_uint32), _p(o, C.c_float), _p(d, C.c_float), _p(s, C.c_uint32)))
+        return o, d, s
+
+    def rng_unilateral(self, seed_lo, seed_hi, n):
+        out = np.empty(n, np.float32)
+        _check(lib().rtx_rng_unilateral(self.handle, seed_lo, seed_hi, n, _p(out, C.c_float)))
+        return out
+
+    def material_bounce(self, mat_index, ray_dir, pos, normal, uv, front, rng_state):
+        f = lambda a, w: np.ascontiguousarray(a, np.float32).reshape(-1, w)
+        rd, po, no, u2 = f(ray_dir, 3), f(pos, 3), f(normal, 3), f(uv, 2)
+        fr = np.ascontiguousarray(front, np.uint8)
+        stt = np.ascontiguousarray(rng_state, np.uint32).reshape(-1, 4).copy()
+        n = len(rd)
+        surf, emit, oo, od = (np.empty((n, 3), np.float32) for _ in range(4))
+        cont = np.empty(n, np.uint8)
+        _check(lib().rtx_material_bounce(self.handle, mat_index, n, _p(rd, C.c_float), _p(po, C.c_float),
+                                         _p(no, C.c_float), _p(u2, C.c_float), _p(fr, C.c_uint8), _p(stt, C.c_uint32),
+                                         _p(surf, C.c_float), _p(emit, C.c_float), _p(oo, C.c_float),
+                                         _p(od, C.c_float), _p(cont, C.c_uint8)))
+        return dict(surface=surf, emitted=emit, out_origin=oo, out_dir=od, cont=cont, rng_state=stt)
+
+    def skybox_color(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.empty_like(d)
+        _check(lib().rtx_skybox_color(self.handle, len(d), _p(d, C.c_float), _p(out, C.c_float)))
+        return out

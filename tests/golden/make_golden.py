@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REAL REFERENCE.
+
+Needs oracle/_ref/ref_parity (the unmodified reference sources + oracle/ref_driver.c, built by
+`make -C oracle ref` in the build container with the pinned flags -O2 -ffp-contract=off).  The
+fixtures are data only — inputs and the reference's outputs — and are what pins both the CPU
+restatement (oracle/oracle.cpp) and the HIP path on machines where /root/reference is absent.
+
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py primary    # one group
+"""
+import hashlib
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from raytracer_amd import assets, scenes  # noqa: E402
+
+REF = os.path.join(REPO, "oracle", "_ref", "ref_parity")
+TMP = os.path.join(assets.cache_dir(), "golden_tmp")
+os.makedirs(TMP, exist_ok=True)
+
+HITREC = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("id", "<u4"), ("t", "<f4"), ("pos", "<f4", 3), ("n", "<f4", 3),
+                   ("uv", "<f4", 2), ("front", "<u4")])
+BOUNCE_IN = np.dtype([("mat", "<u4"), ("dir", "<f4", 3), ("pos", "<f4", 3), ("n", "<f4", 3), ("uv", "<f4", 2),
+                      ("front", "<u4"), ("seed_lo", "<u8"), ("seed_hi", "<u8")])
+BOUNCE_OUT = np.dtype([("cont", "<u4"), ("surf", "<f4", 3), ("emit", "<f4", 3), ("oo", "<f4", 3), ("od", "<f4", 3),
+                       ("draws", "<u4", 4)])
+
+
+def ref(scene, *args):
+    path = scenes.write_recipe(scene)
+    r = subprocess.run([REF, path, assets.cache_dir(), *map(str, args)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-2000:])
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("{") or ln.startswith("[")]
+    return json.loads(last[-1]) if last else None
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+def g_rng():
+    out = {}
+    for lo, hi in [(1, 2), (0x123456789ABCDEF, 0xFEDCBA9876543210), (7, 0)]:
+        r = subprocess.run([REF, "rng", str(lo), str(hi), "64"], capture_output=True, text=True, check=True)
+        out["%d_%d" % (lo, hi)] = json.loads(r.stdout)
+    json.dump(out, open(os.path.join(HERE, "rng.json"), "w"))
+    print("wrote rng.json")
+
+
+def g_kd():
+    out = {}
+    for sc in ["teapot", "bunny", "pear", "materials", "dragon1"]:
+        f = os.path.join(TMP, "kd.bin")
+        st = ref(sc, "kd", f)
+        raw = open(f, "rb").read()
+        _, nn, nr, root, _ = struct.unpack_from("<5I", raw, 0)
+        nodes = np.frombuffer(raw, np.uint32, nn * 2, 20)
+        refs = np.frombuffer(raw, np.uint32, nr, 20 + nn * 8)
+        st.update(root=root, sha256_nodes=hashlib.sha256(nodes.tobytes()).hexdigest(),
+                  sha256_refs=hashlib.sha256(refs.tobytes()).hexdigest())
+        out[sc] = st
+        if sc == "materials":  # tiny tree: keep it whole
+            save("kd_materials.npz", nodes=nodes.reshape(-1, 2), refs=refs)
+    json.dump(out, open(os.path.join(HERE, "kd.json"), "w"), indent=1)
+    print("wrote kd.json")
+
+
+def g_primary():
+    W, H = 1920, 1080
+    sums = {}
+    for sc, step in [("teapot", 12), ("bunny", 12), ("pear", 12), ("materials", 12), ("dragon1", 24)]:
+        f = os.path.join(TMP, "p.bin")
+        for jitter, tag in [(0, "A"), (1, "B")]:
+            full = ref(sc, "primary", W, H, 1, jitter, 1, 2, 1, f)  # full 1080p: checksums only
+            rec = np.fromfile(f, HITREC)
+            sums["%s_%s" % (sc, tag)] = dict(full, width=W, height=H, seed=[1, 2],
+                                             sha256_id=hashlib.sha256(rec["id"].tobytes()).hexdigest(),
+                                             sha256_t=hashlib.sha256(rec["t"].tobytes()).hexdigest())
+            sub = rec.reshape(H, W)[::step, ::step].reshape(-1)
+            save("primary_%s_%s.npz" % (sc, tag), rec=sub, step=np.int32(step), width=np.int32(W), height=np.int32(H))
+    json.dump(sums, open(os.path.join(HERE, "primary_checksums.json"), "w"), indent=1)
+    print("wrote primary_checksums.json")
+
+
+def g_trace():
+    """Incoherent secondary-style rays: origins on/near the mesh, random directions."""
+    rng = np.random.default_rng(20241111)
+    for sc in ["teapot", "bunny", "pear", "materials"]:
+        prim = np.load(os.path.join(HERE, "primary_%s_B.npz" % sc))["rec"]
+        hitp = prim["pos"][prim["id"] != 0xFFFFFFFF]
+        n = 4096
+        o = hitp[rng.integers(0, len(hitp), n)].astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d[: n // 8] *= np.float32(1e-3)  # un-normalised inputs exercise Ray_Make
+        d[n // 8: n // 4, 0] = 0.0       # axis-parallel components exercise the |dir| < eps branch
+        d[n // 4: n // 4 + 64, 1] = np.float32(5e-5)
+        rays = np.concatenate([o, d], axis=1).astype("<f4")
+        fi, fo = os.path.join(TMP, "rays.bin"), os.path.join(TMP, "hits.bin")
+        rays.tofile(fi)
+        ref(sc, "trace", fi, fo)
+        save("trace_%s.npz" % sc, rays=rays, rec=np.fromfile(fo, HITREC))
+
+
+def g_render():
+    for sc, w, h, spp, depth in [("teapot", 96, 54, 8, 8), ("bunny", 96, 54, 8, 8), ("dragon1", 96, 54, 8, 8),
+                                 ("pear", 96, 54, 8, 16), ("materials", 128, 72, 16, 8), ("materials", 64, 36, 4, 1)]:
+        f = os.path.join(TMP, "r.bin")
+        meta = ref(sc, "render", w, h, spp, depth, 1, 2, 8, f)
+        raw = open(f, "rb").read()
+        cum = np.frombuffer(raw, "<f4", w * h * 3, 16).reshape(h, w, 3)
+        bgr = np.frombuffer(raw, np.uint8, w * h * 3, 16 + w * h * 12).reshape(h, w, 3)
+        save("render_%s_%dx%d_%dspp_d%d.npz" % (sc, w, h, spp, depth), cum=cum, bgr=bgr,
+             meta=np.array([w, h, spp, depth, 1, 2], np.int64))
+        print(meta)
+
+
+def g_bounce():
+    rng = np.random.default_rng(7)
+    names = scenes.build("materials").material_order  # m0..m10 in declaration order = driver's index
+    n_per = 96
+    recs = np.zeros(len(names) * n_per, BOUNCE_IN)
+    k = 0
+    for mi in range(len(names)):
+        for j in range(n_per):
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            front = j % 4 != 3
+            if np.dot(d, nrm) > 0:  # unitNormal always faces the ray (HitInfo_SetFaceNormal)
+                d = -d
+            if j % 8 == 7:
+                nrm = nrm * 0.7  # interpolated normals are not unit length
+            if j % 16 == 5:  # grazing incidence
+                t = np.cross(nrm, rng.normal(size=3))
+                t /= np.linalg.norm(t)
+                d = t - 1e-3 * nrm / np.linalg.norm(nrm)
+                d /= np.linalg.norm(d)
+            recs[k] = (mi, d.astype(np.float32), rng.uniform(-10, 10, 3).astype(np.float32), nrm.astype(np.float32),
+                       rng.uniform(0, 1, 2).astype(np.float32), int(front), int(rng.integers(1, 2 ** 62)),
+                       int(rng.integers(1, 2 ** 62)))
+            k += 1
+    fi, fo = os.path.join(TMP, "b_in.bin"), os.path.join(TMP, "b_out.bin")
+    recs.tofile(fi)
+    ref("materials", "bounce", fi, fo)
+    save("bounce_materials.npz", inp=recs, out=np.fromfile(fo, BOUNCE_OUT), names=np.array(names))
+
+
+def g_sky():
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(512, 3)).astype("<f4")
+    d[:6] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.array([1, -1] * 3, np.float32)[:, None]
+    d[6:12] = [[1, 1, 0], [1, -1, 0], [-1, 0, 1], [0, 1, 1], [1, 1, 1], [-1, -1, -1]]
+    fi, fo = os.path.join(TMP, "s_in.bin"), os.path.join(TMP, "s_out.bin")
+    d.tofile(fi)
+    for sc in ["pear"]:
+        ref(sc, "sky", fi, fo)
+        save("sky_%s.npz" % sc, dirs=d, rgb=np.fromfile(fo, "<f4").reshape(-1, 3))
+
+
+GROUPS = dict(rng=g_rng, kd=g_kd, primary=g_primary, trace=g_trace, render=g_render, bounce=g_bounce, sky=g_sky)
+
+if __name__ == "__main__":
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/ref_parity is missing: make -C oracle ref (needs /root/reference)")
+    for g in (sys.argv[1:] or list(GROUPS)):
+        GROUPS[g]()

@@ -1,0 +1,192 @@
+"""Host side (librtx_host.so): OBJ import, SAH kd-tree build, flattener — no GPU.
+
+The kd-tree must be the reference's tree: tests/golden/kd.json holds node/leaf/ref counts and
+SHA-256 digests of the node words and leaf references dumped from the real reference's KDTree_New
+(oracle/ref_driver.c `kd`), for every parity scene including the 278k-triangle dragon stand-in.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import assets, host, scenes
+from util import GOLDEN, golden
+
+KD = json.load(open(os.path.join(GOLDEN, "kd.json")))
+
+
+def _tree_arrays(sc):
+    d = sc.desc.contents
+    w0 = np.ctypeslib.as_array(d.node_w0, (d.n_nodes,))
+    w1 = np.ctypeslib.as_array(d.node_w1, (d.n_nodes,))
+    lr = np.ctypeslib.as_array(d.leaf_ref, (d.n_refs,))
+    tri_obj = np.ctypeslib.as_array(d.tri_obj, (max(d.n_tris, 1),))
+    sph_obj = np.ctypeslib.as_array(d.sph_obj, (max(d.n_spheres, 1),))
+    idx = lr & 0x7FFFFFFF
+    kd = np.where(lr >> 31, sph_obj[np.minimum(idx, len(sph_obj) - 1)], tri_obj[np.minimum(idx, len(tri_obj) - 1)])
+    return np.stack([w0, w1], axis=1).astype(np.uint32), kd.astype(np.uint32), d
+
+
+@pytest.mark.parametrize("scene", list(KD))
+def test_kdtree_is_the_reference_tree(built_scenes, scene):
+    want = KD[scene]
+    nodes, refs, d = _tree_arrays(built_scenes(scene))
+    st = built_scenes(scene).kd_stats()
+    assert (st["nodes"], st["leaves"], st["empty_leaves"], st["refs"], st["max_leaf_len"]) == (
+        want["nodes"], want["leaves"], want["empty_leaves"], want["refs"], want["max_leaf_len"])
+    assert d.root_index == want["root"]
+    assert d.n_tris + d.n_spheres == want["kd_objects"] and d.n_planes == want["unbounded"]
+    assert hashlib.sha256(nodes.tobytes()).hexdigest() == want["sha256_nodes"]
+    assert hashlib.sha256(refs.tobytes()).hexdigest() == want["sha256_refs"]
+
+
+def test_small_tree_node_for_node(built_scenes):
+    g = golden("kd_materials.npz")
+    nodes, refs, _ = _tree_arrays(built_scenes("materials"))
+    assert np.array_equal(nodes, g["nodes"]) and np.array_equal(refs, g["refs"])
+
+
+def test_right_child_is_parent_plus_one_and_indices_in_range(built_scenes):
+    nodes, _, d = _tree_arrays(built_scenes("teapot"))
+    typ, idx = nodes[:, 1] >> 30, nodes[:, 1] & 0x3FFFFFFF
+    inner = typ != 3
+    assert (idx[inner] < d.n_nodes).all() and (np.nonzero(inner)[0] + 1 < d.n_nodes).all()
+    leaf = ~inner
+    assert (idx[leaf].astype(np.int64) + nodes[leaf, 0] <= d.n_refs).all()
+    assert d.max_depth == int(8.0 + 1.8 * np.log2(d.n_tris + d.n_spheres)) + 1
+
+
+def _write(tmp_path, text):
+    p = tmp_path / "m.obj"
+    p.write_text(text)
+    return str(p).encode()
+
+
+def test_obj_import_quads_tris_and_default_normals(tmp_path):
+    L = host.lib()
+    text = ("v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 1\n"
+            "f 1/1/1 2/2/1 3/3/1 4/1/1\nf 1 2 3\nf 1//1 2//1 3//1\nf 1/2 2/3 3/1\n")
+    m = L.Mesh_New()
+    assert L.Mesh_Import_OBJ_Path(m, _write(tmp_path, text))
+    assert L.Mesh_Triangle_Count(m) == 5  # quad -> (0,1,2),(0,2,3) (mesh.c:165-168) + 3 triangles
+    t = L.Mesh_Triangles(m)
+    assert (t[1].vtx[1].pos.x, t[1].vtx[1].pos.y) == (2.0, 2.0) and t[1].vtx[2].pos.y == 2.0  # (0,2,3)
+    assert t[0].vtx[1].tex.x == 1.0 and t[0].vtx[0].norm.z == 1.0
+    # plain triangle: normalised default normal (mesh.c:212-214), uv (0,0)
+    assert (t[2].vtx[0].norm.x, t[2].vtx[0].norm.y, t[2].vtx[0].norm.z) == (0.0, 0.0, 1.0)
+    assert t[2].vtx[2].tex.x == 0.0
+    assert t[3].vtx[0].norm.z == 1.0 and t[4].vtx[0].tex.x == 1.0
+    L.Mesh_Delete(m)
+
+
+def test_obj_import_quad_default_normal_is_not_normalised(tmp_path):
+    L = host.lib()
+    m = L.Mesh_New()
+    assert L.Mesh_Import_OBJ_Path(m, _write(tmp_path, "v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nf 1 2 3 4\n"))
+    t = L.Mesh_Triangles(m)
+    assert t[0].vtx[0].norm.z == 4.0  # cross((2,0,0),(2,2,0)) (mesh.c:179-181)
+    L.Mesh_Delete(m)
+
+
+def test_obj_import_error_paths(tmp_path):
+    L = host.lib()
+    for bad in ["v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3 1 2\n", "v 0 0 0\nf 1 2 3\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 x\n"]:
+        m = L.Mesh_New()
+        assert not L.Mesh_Import_OBJ_Path(m, _write(tmp_path, bad))
+        assert host.last_error()
+        L.Mesh_Delete(m)
+    m = L.Mesh_New()
+    assert not L.Mesh_Import_OBJ_Path(m, b"/nonexistent/file.obj")
+    L.Mesh_Delete(m)
+
+
+def test_packed_meshes_expand_to_reference_triangle_counts():
+    L = host.lib()
+    for name, tris in [("teapot", 6320), ("bunny", 69451), ("pear", 2848)]:
+        m = L.Mesh_New()
+        assert L.Mesh_Import_OBJ_Path(m, assets.obj_path(name).encode())
+        assert L.Mesh_Triangle_Count(m) == tris
+        L.Mesh_Delete(m)
+
+
+def test_mesh_world_transform_is_scale_then_translate(tmp_path):
+    L = host.lib()
+    sky = L.Skybox_New_Color(host.Color(0, 0, 0))
+    scene = L.Scene_New(sky)
+    tex = L.Texture_New()
+    L.Texture_Import_Color(tex, host.Color(1, 1, 1))
+    mat = L.Material_Diffuse_Make(tex)
+    m = L.Mesh_New()
+    assert L.Mesh_Import_OBJ_Path(m, _write(tmp_path, "v 1 2 3\nv 2 2 3\nv 1 3 3\nf 1 2 3\n"))
+    L.Mesh_Set_Material(m, C.byref(mat))
+    L.Mesh_Set_Scale(m, 2.0)
+    L.Mesh_Set_Origin(m, host.point3(10, 20, 30))
+    L.Mesh_AddToScene(m, scene)
+    assert L.Scene_Prepare(scene)
+    flat = L.Scene_Flatten(scene)
+    d = L.SceneFlat_Desc(flat).contents
+    assert d.n_tris == 1 and [d.tri_pos[c] for c in range(3)] == [12.0, 24.0, 36.0]
+    assert [d.tri_nrm[c] for c in range(3)] == [0.0, 0.0, 1.0]  # normals untouched by the transform
+    L.SceneFlat_Delete(flat)
+    L.Mesh_Delete(m)
+    L.Scene_Delete(scene)
+
+
+def test_scene_without_bounded_objects_cannot_be_flattened():
+    L = host.lib()
+    sky = L.Skybox_New_Color(host.Color(0, 0, 0))
+    scene = L.Scene_New(sky)
+    tex = L.Texture_New()
+    L.Texture_Import_Color(tex, host.Color(1, 1, 1))
+    mat = L.Material_Diffuse_Make(tex)
+    o = host.Object()
+    o.material = C.pointer(mat)
+    o.surface = L.Surface_Plane_Make(host.point3(0, 0, 0), host.vec3(0, 0, 1))
+    L.Scene_Add_Object(scene, C.byref(o))
+    assert L.Scene_Prepare(scene)
+    assert not L.Scene_Flatten(scene)  # the reference dereferences a NULL tree here (scene.c:109)
+    L.Scene_Delete(scene)
+
+
+def test_bounding_boxes_are_padded_by_epsilon():
+    L = host.lib()
+    s = L.Surface_Sphere_Make(host.point3(1, 2, 3), 2.0)
+    b = L.Surface_BoundingBox(C.byref(s))
+    eps = np.float32(0.0001)
+    assert b.min.x == float(np.float32(1) - (np.float32(2) + eps)) and b.max.z == float(np.float32(3) + (np.float32(2) + eps))
+    assert L.Surface_Bounded(C.byref(s))
+    p = L.Surface_Plane_Make(host.point3(0, 0, 0), host.vec3(0, 0, 1))
+    assert not L.Surface_Bounded(C.byref(p))
+
+
+def test_bmp_roundtrip_and_texture_linearisation(tmp_path):
+    L = host.lib()
+    rgb = (np.arange(5 * 7 * 3) % 256).astype(np.uint8).reshape(5, 7, 3)  # width 7 -> 3 bytes of row padding
+    path = str(tmp_path / "t.bmp")
+    assets.write_bmp(path, rgb)
+    img = host.ImageRGB()
+    assert L.ImageRGB_Load_BMP_Path(C.byref(img), path.encode())
+    assert (img.res.width, img.res.height) == (7, 5)
+    px = np.ctypeslib.as_array(C.cast(img.pix, C.POINTER(C.c_uint8)), (5, 7, 3))
+    assert np.array_equal(px[:, :, ::-1], rgb)  # RGB{b,g,r}; row 0 = top of the picture (image.c:118)
+    out = str(tmp_path / "o.bmp")
+    assert L.ImageRGB_Save_BMP_Path(C.byref(img), out.encode())
+    L.ImageRGB_Unload(C.byref(img))
+    tex = L.Texture_New()
+    assert L.Texture_Import_BMP_Path(tex, path.encode())
+    im = L.Texture_Image(tex).contents
+    lin = np.ctypeslib.as_array(C.cast(im.pix, C.POINTER(C.c_float)), (5, 7, 3))
+    s = rgb.astype(np.float32) / np.float32(255)
+    want = np.where(s < 0.04045, s / np.float32(12.92), ((s + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4))
+    assert np.allclose(lin, want, rtol=1e-6, atol=1e-7)
+    L.Texture_Delete(tex)
+
+
+def test_camera_block_layout_matches_rtx_camera(built_scenes):
+    cam = built_scenes("teapot").rtx_camera()
+    assert list(cam.origin) == [20.0, -20.0, 20.0] and cam.lens_radius == 0.0
+    w = np.array(list(cam.w))
+    assert abs(np.linalg.norm(w) - 1) < 1e-6
