@@ -70,8 +70,10 @@ def recipe(name: str) -> list:
             if i in (3, 4):
                 continue
             lines.append("sphere %g %g 6 4.5 m%d" % (-30 + 10 * (i % 6), 10 if i < 6 else -4, i))
-        lines += ["sphere 20 20 10 8 m3", "triangle -8 -14 0.5  8 -14 0.5  0 -10 7 m5",
-                  "triangle -8 -14 0.5  0 -10 7  -12 -8 3 m10", "plane 0 0 0 0 0 1 m4"]
+        # two loose triangles through the OBJ path (textured Disney diffuse) + one small one built
+        # with Triangle_MakeSimple (un-normalised normal, Lambert: harmless there)
+        lines += ["sphere 20 20 10 8 m3", "mesh %s m5 1 0 0 0" % _rel(assets.tiny_mesh()),
+                  "triangle 14 -12 0.5  18 -12 0.5  16 -10 4 m0", "plane 0 0 0 0 0 1 m4"]
         return lines
     raise KeyError(name)
 
