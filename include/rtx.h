@@ -172,6 +172,7 @@ typedef struct rtx_stats {
     double   ms_resolve;
     uint32_t trace_launches;
     uint32_t passes; /* slabs */
+    double   ms_trace_at_depth[RTX_MAX_DEPTH]; /* closest-hit kernel time per ray depth */
 } rtx_stats;
 
 /* ---- library ---- */

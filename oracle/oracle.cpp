@@ -1106,10 +1106,11 @@ static inline uint8_t LinearTosRGB(f32 channel)
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o, const float* dxyz, int unit_dir, uint32_t* pid, float* t,
-                            float* pos, float* nrm, float* uv, uint8_t* front, uint64_t* visits3)
+                            float* pos, float* nrm, float* uv, uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
     Scene sc = {desc, 0, 0, 0};
     for (size_t i = 0; i < n; i++) {
+        const u64 before = sc.nInner + sc.nLeaf + sc.nPrim;
         vec3 org = vec(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
         vec3 dir = vec(dxyz[3 * i], dxyz[3 * i + 1], dxyz[3 * i + 2]);
         Ray  ray = unit_dir ? Ray_FromUnit(org, dir) : Ray_Make(org, dir);
@@ -1124,6 +1125,7 @@ extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o
         if (nrm) nrm[3 * i] = hit.unitNormal.x, nrm[3 * i + 1] = hit.unitNormal.y, nrm[3 * i + 2] = hit.unitNormal.z;
         if (uv) uv[2 * i] = hit.uv.x, uv[2 * i + 1] = hit.uv.y;
         if (front) front[i] = h && hit.frontFace ? 1 : 0;
+        if (steps_per_ray) steps_per_ray[i] = (u32)(sc.nInner + sc.nLeaf + sc.nPrim - before);
     }
     if (visits3) visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
     return 0;

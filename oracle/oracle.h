@@ -26,7 +26,7 @@ extern "C" {
  * visits (may be NULL) receives {inner nodes, leaves, primitive tests} summed over the rays. */
 int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* origin_xyz, const float* dir_xyz, int unit_dir,
                  uint32_t* prim_id, float* t, float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face,
-                 uint64_t* visits3);
+                 uint64_t* visits3, uint32_t* steps_per_ray /* inner+leaf+prim visits of each ray, or NULL */);
 
 /* Seeded RenderPixel over the frame partition described by params (same meaning as rtx_render).
  * cum_out: W*H*3 f32 sums (rows not assigned are left untouched); bgr_out: W*H*3 u8 or NULL.

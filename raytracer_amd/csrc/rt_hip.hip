@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -75,6 +76,7 @@ struct rtx_scene {
     // frames so that a render loop does not pay hipMalloc/hipFree of gigabytes per frame
     void*    ws;
     uint64_t ws_bytes;
+    unsigned persist_blocks[2]; // resident grid of k_trace_persist<false/true> (0 = not queried yet)
 };
 
 static int workspace(rtx_scene* sc, uint64_t bytes, char** out)
@@ -191,6 +193,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     sc->n_ev      = 0;
     sc->ws        = nullptr;
     sc->ws_bytes  = 0;
+    sc->persist_blocks[0] = sc->persist_blocks[1] = 0;
     memset(&sc->dev, 0, sizeof sc->dev);
     SceneDev& S = sc->dev;
 
@@ -204,31 +207,59 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         for (uint32_t i = 0; i < d->n_nodes; i++) nodes[i] = make_uint2(d->node_w0[i], d->node_w1[i]);
         UP(upload(sc, nodes.data(), nodes.size(), &S.nodes));
     }
-    UP(upload(sc, d->leaf_ref, d->n_refs, &S.leaf_ref));
     {
-        const size_t        T = d->n_tris;
-        std::vector<float4> hot(3 * T), cold(4 * T);
-        for (size_t i = 0; i < T; i++) {
-            float p[9], nn[9], uv[6];
+        // Device-side triangle order = order of first appearance in the leaf reference stream (the
+        // tree's depth-first leaf order).  Triangles of one leaf, and of leaves that are neighbours
+        // in space, then share cache lines; rocprof showed the bounce passes bound by L2-miss traffic
+        // (one 128-B line per 48-B triangle fetched at random).  Only addresses change: tri_obj keeps
+        // the reference's kdObjects index of every triangle.
+        const size_t          T = d->n_tris;
+        std::vector<uint32_t> new_of_old(T, 0xFFFFFFFFu), old_of_new;
+        old_of_new.reserve(T);
+        for (uint32_t k = 0; k < d->n_refs; k++) {
+            uint32_t r = d->leaf_ref[k];
+            if (!(r & RTX_REF_SPHERE) && new_of_old[r] == 0xFFFFFFFFu) {
+                new_of_old[r] = (uint32_t)old_of_new.size();
+                old_of_new.push_back(r);
+            }
+        }
+        for (uint32_t i = 0; i < T; i++)
+            if (new_of_old[i] == 0xFFFFFFFFu) {
+                new_of_old[i] = (uint32_t)old_of_new.size();
+                old_of_new.push_back(i);
+            }
+        std::vector<uint32_t> refs(d->n_refs);
+        for (uint32_t k = 0; k < d->n_refs; k++) {
+            uint32_t r = d->leaf_ref[k];
+            refs[k]    = (r & RTX_REF_SPHERE) ? r : new_of_old[r];
+        }
+        UP(upload(sc, refs.data(), refs.size(), &S.leaf_ref));
+
+        std::vector<float4>   hot(3 * T), cold(4 * T);
+        std::vector<uint32_t> obj(T);
+        for (size_t j = 0; j < T; j++) {
+            const size_t i = old_of_new[j];
+            float        p[9], nn[9], uv[6];
             for (int c = 0; c < 9; c++) p[c] = d->tri_pos[c * T + i], nn[c] = d->tri_nrm[c * T + i];
             for (int c = 0; c < 6; c++) uv[c] = d->tri_uv[c * T + i];
             // edge1 = v1 - v0, edge2 = v2 - v0 (surfaces.c:137-138), one binary32 subtraction each
             float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
             float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
-            hot[3 * i + 0]  = make_float4(p[0], p[1], p[2], e1x);
-            hot[3 * i + 1]  = make_float4(e1y, e1z, e2x, e2y);
-            hot[3 * i + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+            hot[3 * j + 0]  = make_float4(p[0], p[1], p[2], e1x);
+            hot[3 * j + 1]  = make_float4(e1y, e1z, e2x, e2y);
+            hot[3 * j + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
             uint32_t mat    = d->tri_mat[i];
             float    matf;
             memcpy(&matf, &mat, 4);
-            cold[4 * i + 0] = make_float4(nn[0], nn[1], nn[2], nn[3]);
-            cold[4 * i + 1] = make_float4(nn[4], nn[5], nn[6], nn[7]);
-            cold[4 * i + 2] = make_float4(nn[8], uv[0], uv[1], uv[2]);
-            cold[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], matf);
+            cold[4 * j + 0] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+            cold[4 * j + 1] = make_float4(nn[4], nn[5], nn[6], nn[7]);
+            cold[4 * j + 2] = make_float4(nn[8], uv[0], uv[1], uv[2]);
+            cold[4 * j + 3] = make_float4(uv[3], uv[4], uv[5], matf);
+            obj[j]          = d->tri_obj[i];
         }
         UP(upload(sc, hot.data(), hot.size(), &S.tri));
         UP(upload(sc, cold.data(), cold.size(), &S.tri_shade));
-        UP(upload(sc, d->tri_obj, T, &S.tri_obj));
+        UP(upload(sc, obj.data(), T, &S.tri_obj));
     }
     {
         const size_t          Sn = d->n_spheres;
@@ -384,6 +415,412 @@ __global__ __launch_bounds__(64) void k_trace(SceneDev S, const float* __restric
         hits[1 * hstride + i] = __float_as_uint(t);
         hits[2 * hstride + i] = __float_as_uint(u);
         hits[3 * hstride + i] = __float_as_uint(v);
+    }
+    if (COUNT) add_visits(counters, vis);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent-wave closest hit with lane refill.
+//
+// Why: on incoherent bounce rays the one-ray-per-thread kernel above keeps a whole wave resident
+// until its slowest lane finishes; rocprof showed ~8 of 64 lanes active per VALU instruction there
+// (a ray that threads through the dense part of the tree without hitting anything walks thousands
+// of cells, its 63 neighbours a few dozen).  Here a fixed grid of waves stays resident; every wave
+// owns a private chunk [next,end) of the ray queue (one atomic per chunk) and, whenever at least
+// REFILL_MIN of its lanes are idle, hands fresh rays to exactly those lanes (ballot + prefix
+// popcount).  Lanes therefore run different rays at different stages of the same traversal state
+// machine:
+//     phase A  descend inner nodes until this lane stands on a non-empty leaf (kdtree.c:501-570)
+//     phase B  test the leaf's primitives one per iteration (kdtree.c:475-499)
+//     then     hit → finish; miss → pop (far child, OUTER tMax) or finish as a miss
+// The per-ray visiting order, comparisons and arithmetic are exactly those of closest_hit().
+// Every wave leaves its loop once the work counter is past n and its own lanes are idle.
+// ---------------------------------------------------------------------------------------------
+#define REFILL_MIN 16
+
+DEV uint64_t wave_bcast_u64(uint64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+                                                       uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
+                                                       uint32_t chunk, uint64_t* counters)
+{
+    const uint32_t lane    = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    uint64_t next = 0, end = 0; // wave-uniform: this wave's private slice of the queue
+    bool     exhausted = false; // wave-uniform: the global counter ran past n
+    bool     active    = false; // this lane holds a ray
+
+    f3       o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), odd = mk3(0, 0, 0);
+    uint64_t ridx = 0;
+    uint32_t node = 0;
+    float    tMax = RTX_INF;
+    int      sp   = 0;
+    uint2    stk[RTX_STACK];
+    bool     inLeaf = false, finish = false;
+    uint32_t leafPos = 0, leafEnd = 0;
+    float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
+    uint32_t best = HIT_MISS;
+    Visits   vis  = {0, 0, 0};
+
+    for (;;) {
+        // ---------------- refill idle lanes ----------------
+        const uint64_t idle  = __ballot(!active);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!exhausted && nidle >= REFILL_MIN) {
+            if (next >= end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(work, (unsigned long long)chunk);
+                base = wave_bcast_u64(base);
+                if (base >= n) {
+                    exhausted = true;
+                } else {
+                    next = base;
+                    end  = base + chunk < n ? base + chunk : n;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t avail = (uint32_t)(end - next);
+                const uint32_t take  = nidle < avail ? nidle : avail;
+                const uint32_t rank  = (uint32_t)__popcll(idle & lt_mask);
+                if (!active && rank < take) {
+                    ridx = next + rank;
+                    o    = mk3(rays[0 * stride + ridx], rays[1 * stride + ridx], rays[2 * stride + ridx]);
+                    d    = mk3(rays[3 * stride + ridx], rays[4 * stride + ridx], rays[5 * stride + ridx]);
+                    inv  = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13)
+                    odd  = vdivc(o, d);
+                    // keep the six quotients in registers: without this the optimiser sinks the
+                    // divisions behind the per-node axis select and redoes one per node visit
+                    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                    node   = S.root;
+                    tMax   = RTX_INF;
+                    sp     = 0;
+                    inLeaf = false;
+                    active = true;
+                }
+                next += take;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const uint32_t stop_idle = exhausted ? 64u : (uint32_t)REFILL_MIN;
+
+        // ---------------- traverse until enough lanes have finished ----------------
+        do {
+            // phase A: inner nodes (and empty leaves) until this lane stands on a leaf with primitives
+            while (active && !inLeaf) {
+                const uint2    nd   = S.nodes[node];
+                const uint32_t type = nd.y >> 30;
+                const uint32_t idx  = nd.y & 0x3FFFFFFFu;
+                if (type == 3u) {
+                    if (COUNT) vis.leaf++;
+                    if (nd.x != 0u) {
+                        inLeaf  = true;
+                        leafPos = idx;
+                        leafEnd = idx + nd.x;
+                        bestT   = RTX_INF;
+                        best    = HIT_MISS;
+                    } else if (sp > 0) { // empty leaf: no hit, resume the pending far child
+                        const uint2 e = stk[--sp];
+                        node          = e.x;
+                        tMax          = __uint_as_float(e.y);
+                    } else { // tree exhausted: no bounded hit
+                        active = false;
+                        finish = true;
+                        best   = HIT_MISS;
+                    }
+                } else {
+                    if (COUNT) vis.inner++;
+                    const float    split = __uint_as_float(nd.x);
+                    const uint32_t right = node + 1;
+                    const bool     ax0 = type == 0u, ax1 = type == 1u;
+                    const float    dA   = ax0 ? d.x : (ax1 ? d.y : d.z);
+                    const float    oA   = ax0 ? o.x : (ax1 ? o.y : o.z);
+                    const float    invA = ax0 ? inv.x : (ax1 ? inv.y : inv.z);
+                    const float    oddA = ax0 ? odd.x : (ax1 ? odd.y : odd.z);
+                    const bool     par    = fabsf(dA) < RT_EPSILON;               // kdtree.c:509
+                    const float    tI     = split * invA - oddA;                  // :518
+                    const float    tMaxN  = minf_(tMax, tI);                      // :519
+                    const bool     behind = tI < RT_EPSILON;                      // :521
+                    const bool     both   = !par && !behind;                      // :537
+                    // side of the origin: >= for the parallel and the two-sided case (:511,:544); for the
+                    // "plane behind" case > / < and, on equality, the sign of Ray_At(100) (:523-535)
+                    const bool ge      = oA >= split;
+                    const bool tie     = oA == split;
+                    const bool tieSide = (oA + 100.0f * dA) >= split;
+                    const bool goRight = (!par && behind && tie) ? tieSide : ge;
+                    const uint32_t nearN = goRight ? right : idx;
+                    if (both && tMaxN == tI) { // :551/:563 far child stays pending with the OUTER tMax
+                        stk[sp++] = make_uint2(goRight ? idx : right, __float_as_uint(tMax));
+                    }
+                    node = nearN;
+                    tMax = both ? tMaxN : tMax;
+                }
+            }
+            // phase B: one primitive per iteration
+            while (active && inLeaf) {
+                const uint32_t r = S.leaf_ref[leafPos];
+                if (COUNT) vis.prim++;
+                float t, u = 0.0f, v = 0.0f;
+                bool  hit;
+                if (r & RTX_REF_SPHERE) {
+                    hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
+                } else {
+                    const float4* tp = S.tri + 3ull * r;
+                    const float4  a = tp[0], b = tp[1], c = tp[2];
+                    hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, RT_EPSILON, tMax, t, u, v);
+                }
+                if (hit && t < bestT) { // strict: first in list wins ties (kdtree.c:485)
+                    bestT = t;
+                    best  = r;
+                    bu    = u;
+                    bv    = v;
+                }
+                if (++leafPos == leafEnd) {
+                    inLeaf = false;
+                    if (best != HIT_MISS) { // a leaf that reports a hit ends the walk
+                        active = false;
+                        finish = true;
+                    } else if (sp > 0) {
+                        const uint2 e = stk[--sp];
+                        node          = e.x;
+                        tMax          = __uint_as_float(e.y);
+                    } else {
+                        active = false;
+                        finish = true;
+                    }
+                }
+            }
+            if (finish) {
+                // Scene_ClosestHitInArray over the unbounded list, then the merge of scene.c:122-142
+                uint32_t ref = best;
+                float    tH = bestT, uH = bu, vH = bv;
+                float    pBest = RTX_INF;
+                uint32_t pRef  = HIT_MISS;
+                for (uint32_t i = 0; i < S.n_planes; i++) {
+                    const float* pl = S.plane + 8ull * i;
+                    float        tp2;
+                    if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                        pBest = tp2;
+                        pRef  = HIT_PLANE | i;
+                    }
+                }
+                if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
+                if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f;
+                hits[0 * hstride + ridx] = ref;
+                hits[1 * hstride + ridx] = __float_as_uint(tH);
+                hits[2 * hstride + ridx] = __float_as_uint(uH);
+                hits[3 * hstride + ridx] = __float_as_uint(vH);
+                finish = false;
+            }
+        } while ((uint32_t)__popcll(__ballot(!active)) < stop_idle);
+    }
+    if (COUNT) add_visits(counters, vis);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flat state-machine variant of the persistent kernel.  rocprof showed k_trace_persist to be
+// instruction-issue bound with as many scalar (exec-mask bookkeeping) as vector instructions: the
+// nested while loops with loop-carried booleans make the structurizer emit ~25 SALU ops per step.
+// Here every lane carries ONE state word and each iteration of the single loop runs at most four
+// flat, independently skippable blocks:
+//     INNER  one kd node (inner step, or arrival at a leaf)        kdtree.c:458-473,501-570
+//     LEAF   one primitive of the current leaf                      kdtree.c:475-499
+//     POP    resume the pending far child, or run out of tree       (the `return false` chain)
+//     FIN    merge with the unbounded list, write the hit record    scene.c:100-143
+// The inner step is written with selects only (its one memory side effect, the push, is a
+// predicated store), and the leaf keeps the NEXT leaf reference in flight while testing the
+// current primitive.
+// ---------------------------------------------------------------------------------------------
+enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2 };
+#ifndef LDS_SLOTS
+#define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave
+#endif
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+                                                    uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
+                                                    uint32_t chunk, uint64_t* counters)
+{
+    const uint32_t lane    = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    uint64_t next = 0, end = 0; // wave-uniform
+    bool     exhausted = false; // wave-uniform
+    int      state     = ST_IDLE;
+
+    f3       o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), odd = mk3(0, 0, 0);
+    uint64_t ridx = 0;
+    uint32_t node = 0;
+    float    tMax = RTX_INF;
+    // Traversal stack: the top LDS_SLOTS entries of every lane live in LDS ([slot][lane], 8-byte
+    // entries, conflict-free); older entries spill one at a time to the per-lane scratch array and
+    // come back one at a time.  With the whole stack in scratch the 6144 resident waves kept ~30 MB
+    // of stack lines alive and evicted the kd-tree from the 8 x 4 MB L2s (rocprof: TCC hit rate 50 %).
+    __shared__ uint2 s_stk[4 * LDS_SLOTS * 64];
+    uint2* const     lstk = s_stk + (threadIdx.x >> 6) * (LDS_SLOTS * 64) + lane;
+    int      sp   = 0;   // stack height
+    int      base = 0;   // entries [base, sp) are in LDS, [0, base) in scratch
+    uint2    stk[RTX_STACK];
+    uint32_t leafPos = 0, leafEnd = 0, curRef = 0;
+    float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
+    uint32_t best = HIT_MISS;
+    Visits   vis  = {0, 0, 0};
+
+    for (;;) {
+        const uint64_t idle  = __ballot(state == ST_IDLE);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (exhausted && nidle == 64u) break;
+        if (!exhausted && nidle >= REFILL_MIN) {
+            if (next >= end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(work, (unsigned long long)chunk);
+                base = wave_bcast_u64(base);
+                if (base >= n) {
+                    exhausted = true;
+                } else {
+                    next = base;
+                    end  = base + chunk < n ? base + chunk : n;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t avail = (uint32_t)(end - next);
+                const uint32_t take  = nidle < avail ? nidle : avail;
+                const uint32_t rank  = (uint32_t)__popcll(idle & lt_mask);
+                if (state == ST_IDLE && rank < take) {
+                    ridx = next + rank;
+                    o    = mk3(rays[0 * stride + ridx], rays[1 * stride + ridx], rays[2 * stride + ridx]);
+                    d    = mk3(rays[3 * stride + ridx], rays[4 * stride + ridx], rays[5 * stride + ridx]);
+                    inv  = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13)
+                    odd  = vdivc(o, d);
+                    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                    node  = S.root;
+                    tMax  = RTX_INF;
+                    sp    = 0;
+                    base  = 0;
+                    state = ST_INNER;
+                }
+                next += take;
+            }
+            continue;
+        }
+
+        bool pop = false, fin = false;
+        if (state == ST_INNER) {
+            const uint2    nd   = S.nodes[node];
+            const uint32_t type = nd.y >> 30;
+            const uint32_t idx  = nd.y & 0x3FFFFFFFu;
+            if (type == 3u) {
+                if (COUNT) vis.leaf++;
+                if (nd.x != 0u) {
+                    state   = ST_LEAF;
+                    leafPos = idx;
+                    leafEnd = idx + nd.x;
+                    bestT   = RTX_INF;
+                    best    = HIT_MISS;
+                    curRef  = S.leaf_ref[idx];
+                } else {
+                    pop = true; // empty leaf: no hit here
+                }
+            } else {
+                if (COUNT) vis.inner++;
+                const float    split = __uint_as_float(nd.x);
+                const uint32_t right = node + 1;
+                const bool     ax0 = type == 0u, ax1 = type == 1u;
+                const float    dA   = ax0 ? d.x : (ax1 ? d.y : d.z);
+                const float    oA   = ax0 ? o.x : (ax1 ? o.y : o.z);
+                const float    invA = ax0 ? inv.x : (ax1 ? inv.y : inv.z);
+                const float    oddA = ax0 ? odd.x : (ax1 ? odd.y : odd.z);
+                const bool     par    = fabsf(dA) < RT_EPSILON; // kdtree.c:509
+                const float    tI     = split * invA - oddA;    // :518
+                const float    tMaxN  = minf_(tMax, tI);        // :519
+                const bool     behind = tI < RT_EPSILON;        // :521
+                const bool     both   = !par && !behind;        // :537
+                const bool     ge      = oA >= split;           // :511, :544
+                const bool     tieSide = (oA + 100.0f * dA) >= split; // Ray_At(ray,100)[axis], :529-535
+                const bool     goRight = (!par && behind && oA == split) ? tieSide : ge;
+                if (both && tMaxN == tI) { // :551/:563 far child pending with the OUTER tMax
+                    if (sp - base == LDS_SLOTS) { // window full: the oldest resident entry goes to scratch
+                        stk[base] = lstk[(base & (LDS_SLOTS - 1)) * 64];
+                        base++;
+                    }
+                    lstk[(sp & (LDS_SLOTS - 1)) * 64] = make_uint2(goRight ? idx : right, __float_as_uint(tMax));
+                    sp++;
+                }
+                node = goRight ? right : idx;
+                tMax = both ? tMaxN : tMax;
+            }
+        } else if (state == ST_LEAF) {
+            const uint32_t r = curRef;
+            if (leafPos + 1 < leafEnd) curRef = S.leaf_ref[leafPos + 1]; // next reference in flight
+            if (COUNT) vis.prim++;
+            float t, u = 0.0f, v = 0.0f;
+            bool  hit;
+            if (r & RTX_REF_SPHERE) {
+                hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
+            } else {
+                const float4* tp = S.tri + 3ull * r;
+                const float4  a = tp[0], b = tp[1], c = tp[2];
+                hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, RT_EPSILON, tMax, t, u, v);
+            }
+            if (hit && t < bestT) { // strict: first in list wins ties (kdtree.c:485)
+                bestT = t;
+                best  = r;
+                bu    = u;
+                bv    = v;
+            }
+            if (++leafPos == leafEnd) {
+                if (best != HIT_MISS) fin = true; // a leaf that reports a hit ends the walk
+                else pop = true;
+            }
+        }
+        if (pop) {
+            if (sp > 0) {
+                sp--;
+                uint2 e;
+                if (sp >= base) {
+                    e = lstk[(sp & (LDS_SLOTS - 1)) * 64];
+                } else { // window empty: take the entry back from scratch
+                    e    = stk[sp];
+                    base = sp;
+                }
+                node          = e.x;
+                tMax          = __uint_as_float(e.y);
+                state         = ST_INNER;
+            } else { // tree exhausted
+                best = HIT_MISS;
+                fin  = true;
+            }
+        }
+        if (fin) {
+            uint32_t ref = best;
+            float    tH = bestT, uH = bu, vH = bv;
+            if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
+            float    pBest = RTX_INF;
+            uint32_t pRef  = HIT_MISS;
+            for (uint32_t i = 0; i < S.n_planes; i++) { // Scene_ClosestHitInArray (scene.c:73-98)
+                const float* pl = S.plane + 8ull * i;
+                float        tp2;
+                if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                    pBest = tp2;
+                    pRef  = HIT_PLANE | i;
+                }
+            }
+            if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f; // scene.c:122-142
+            hits[0 * hstride + ridx] = ref;
+            hits[1 * hstride + ridx] = __float_as_uint(tH);
+            hits[2 * hstride + ridx] = __float_as_uint(uH);
+            hits[3 * hstride + ridx] = __float_as_uint(vH);
+            state = ST_IDLE;
+        }
     }
     if (COUNT) add_visits(counters, vis);
 }
@@ -605,17 +1042,53 @@ struct DevBuf { // RAII device buffer for the host-pointer entry points
     template <typename T> T* as() { return (T*)p; }
 };
 
+static int trace_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RTX_TRACE_VARIANT"); // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine
+        v             = e ? atoi(e) : 2;
+    }
+    return v;
+}
+
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
                         bool count, uint64_t* d_counters)
 {
     if (n == 0) return RTX_OK;
     if (n > (uint64_t)0x7FFFFFFF * 64) return fail(RTX_E_LIMIT, "too many rays for one launch");
-    unsigned nb = blocks_for(n, 64);
-    if (count) {
-        hipLaunchKernelGGL(k_trace<true>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
-    } else {
-        hipLaunchKernelGGL(k_trace<false>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
+    if (trace_variant() == 0) {
+        unsigned nb = blocks_for(n, 64);
+        if (count) {
+            hipLaunchKernelGGL(k_trace<true>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
+        } else {
+            hipLaunchKernelGGL(k_trace<false>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
+        }
+        HIPCHECK(hipGetLastError());
+        return RTX_OK;
     }
+    // persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
+    // that would not fit simply start later and find the queue empty — nothing waits on another block)
+    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*);
+    const int     variant = trace_variant();
+    PersistKernel kern    = variant == 1 ? (count ? k_trace_persist<true> : k_trace_persist<false>) : (count ? k_trace_flat<true> : k_trace_flat<false>);
+    if (sc->persist_blocks[count ? 1 : 0] == 0) {
+        int per_cu = 0, cus = 0;
+        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
+        HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        sc->persist_blocks[count ? 1 : 0] = (unsigned)(per_cu * cus);
+    }
+    unsigned long long* work = (unsigned long long*)&sc->d_counters[8];
+    HIPCHECK(hipMemsetAsync(work, 0, sizeof(unsigned long long), st));
+    const unsigned resident = sc->persist_blocks[count ? 1 : 0];
+    const uint64_t waves    = (uint64_t)resident * 4;
+    // chunk: about 8 grabs per wave on big queues, never below one wave's worth
+    uint64_t chunk = n / (waves * 8);
+    chunk          = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+    unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + 255) / 256);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
@@ -758,7 +1231,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         return RTX_OK;
     }
     // slab sizing: whole pixels, at most `budget` paths in flight
-    uint64_t budget = p->max_paths_in_flight ? p->max_paths_in_flight : (32ull << 20);
+    uint64_t budget = p->max_paths_in_flight ? p->max_paths_in_flight : (160ull << 20); // whole 1080p/64spp frame: 133 M paths, 18.6 GB of 288
     if (budget > 0xFFFFFF00ull) budget = 0xFFFFFF00ull; // path ids are u32
     uint64_t px_per_slab = std::max<uint64_t>(1, budget / g.n_samples);
     px_per_slab          = std::min(px_per_slab, n_pixels);
@@ -781,8 +1254,9 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     if ((rc = get_event(sc, nev++, &evA)) != RTX_OK) return rc;
     if ((rc = get_event(sc, nev++, &evB)) != RTX_OK) return rc;
     HIPCHECK(hipEventRecord(evA, st));
-    struct Span { int a, b, kind; };
+    struct Span { int a, b, kind; uint32_t depth; };
     std::vector<Span> spans;
+    uint32_t cur_depth = 0;
     auto timed = [&](int kind, auto&& launch) -> int {
         hipEvent_t a, b;
         int        ia = nev, ib = nev + 1, r;
@@ -792,7 +1266,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         launch();
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(b, st));
-        spans.push_back({ia, ib, kind});
+        spans.push_back({ia, ib, kind, cur_depth});
         return RTX_OK;
     };
 
@@ -808,6 +1282,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         for (uint32_t depth = 0; depth < p->max_depth && n > 0; depth++) {
             local.rays_at_depth[depth] += n;
             local.rays_total += n;
+            cur_depth = depth;
             rc = timed(1, [&] { (void)launch_trace(sc, q[cur].base, cap, n, hits.base, cap, st, count, sc->d_counters); });
             if (rc != RTX_OK) return rc;
             local.trace_launches++;
@@ -839,6 +1314,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     for (const Span& s : spans) {
         HIPCHECK(hipEventElapsedTime(&ms, sc->ev[s.a], sc->ev[s.b]));
         (s.kind == 0 ? local.ms_raygen : s.kind == 1 ? local.ms_trace : s.kind == 2 ? local.ms_shade : local.ms_resolve) += ms;
+        if (s.kind == 1) local.ms_trace_at_depth[s.depth] += ms;
     }
     uint64_t c[5];
     HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
