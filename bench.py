@@ -30,11 +30,12 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def alg_bytes(vi, vl, vp, rays):
-    """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d):
-    8 B per inner node + 8 B per leaf + (4 B leaf ref + 36 B vertex positions) per primitive test
-    + 64 B ray record read + 44 B hit record write per ray."""
-    return 8 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
+def alg_bytes(vi, vl, vp, vc, rays):
+    """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d), for the walk the kernel actually does
+    (subtree-box culling on): every node it fetches — inner, leaf, or fetched and culled — is the 8-B kd
+    node + its 24-B box = 32 B; (4 B leaf ref + 36 B vertex positions) per primitive test;
+    64 B ray record read + 44 B hit record write per ray.  The N_* are the kernel's own counters."""
+    return 32 * (vi + vl + vc) + 40 * vp + (64 + 44) * rays
 
 
 def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):
@@ -132,9 +133,11 @@ def main():
 
     rays_rank = float(sum(s["rays_total"] for s in stats))
     vals = torch.tensor([dt, rays_rank, sum(s["ms_trace"] for s in stats), float(sum(s["trace_launches"] for s in stats)),
-                         float(alg_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["rays_total"])),
+                         float(alg_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["visits_culled"],
+                                         st_count["rays_total"])),
                          float(st_count["rays_total"]), float(st_count["visits_inner"]), float(st_count["visits_leaf"]), float(st_count["visits_prim"]),
-                         sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats)],
+                         sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats),
+                         float(st_count["visits_culled"])],
                         dtype=torch.float64, device=dev)
     tmax = vals[:1].clone()
     if world > 1:
@@ -166,11 +169,12 @@ def main():
                                       args.height, args.spp, args.depth, args.split),
                        "scene": args.scene, "triangles": int(sc.desc.contents.n_tris), "kd_nodes": int(sc.desc.contents.n_nodes),
                        "rays_per_frame": rays_frame, "rays_per_camera_path": rays_frame / (args.width * args.height * args.spp),
-                       "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame},
+                       "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame,
+                                          "fetched_and_culled": v[12] / rays_frame},
                        "kernel_ms_per_frame": {"trace": ms_trace / args.steps / world, "shade": v[9] / args.steps / world,
                                                "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
+                         "traffic": traffic, "kernel": "k_trace_flat<false,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
                          "alg_bytes_per_ray": bytes_frame / rays_frame},
         }
         if world == 1 and not args.no_cpu_baseline:

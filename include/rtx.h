@@ -158,6 +158,8 @@ typedef struct rtx_render_params {
 #define RTX_RENDER_COUNT_VISITS 1u /* also count kd-tree visits (slower kernel variant)      */
 #define RTX_RENDER_PIXEL_CENTRES 2u /* replace the two jitter draws by 0.5 (config-1 ray set A) */
 #define RTX_TRACE_UNIT_DIR 4u /* rtx_trace_closest: dir_xyz already went through Ray_Make; use as is */
+#define RTX_TRACE_LITERAL 8u  /* closest hit by the literal kd walk (kdtree.c:453-577 step for step), without
+                               * the subtree-box culling; same results, more node visits */
 
 typedef struct rtx_stats {
     uint64_t rays_total;
@@ -173,6 +175,7 @@ typedef struct rtx_stats {
     uint32_t trace_launches;
     uint32_t passes; /* slabs */
     double   ms_trace_at_depth[RTX_MAX_DEPTH]; /* closest-hit kernel time per ray depth */
+    uint64_t visits_culled; /* nodes fetched and skipped by the box test (COUNT_VISITS, culled walk) */
 } rtx_stats;
 
 /* ---- library ---- */
@@ -185,6 +188,11 @@ int         rtx_device_count(int* count);
 int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
 int rtx_scene_destroy(rtx_scene* scene);
 int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
+/* Parity seam for the culled walk (host only, needs no device): the conservative subtree boxes
+ * rtx_scene_create uploads (boxes6: n_nodes x {min xyz, max xyz}) and {centre xyz, origin radius^2,
+ * tMax stretch} (info5), so that a CPU checker can replay the very same culling decisions.  No
+ * counterpart in the reference (its KDTree.worldBox, kdtree.c:435, is never used by the traversal). */
+int rtx_cull_data_build(const rtx_scene_desc* desc, float* boxes6, float* info5);
 
 /* ---- ray-level parity seam: batched Scene_ClosestHit (src/world/scene.h:12).
  * Host pointers, interleaved xyz.  dir need not be normalised: Ray_Make (src/rt/ray.c:3-16)
@@ -197,7 +205,7 @@ int rtx_trace_closest(rtx_scene* scene, size_t n, const float* origin_xyz, const
  * normalised by a previous Ray_Make; writes prim ref/t/u/v (4 x n dwords, SoA) to `hits`.
  * Asynchronous on `stream` (a hipStream_t); this is the entry bench.py times. */
 int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, uint32_t* d_hits,
-                             void* stream, uint32_t flags, uint64_t* d_visit_counters);
+                             void* stream, uint32_t flags, uint64_t* d_visit_counters /* 4 x u64: inner, leaf, prim, culled */);
 
 /* ---- frame-level seam: replaces Render_Worker/RenderTile/RenderPixel/RayColor
  *      (src/rt/renderer.c:54-178).  Blocking.  bgr_out = ImageRGB.pix (RGB{b,g,r},

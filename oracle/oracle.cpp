@@ -262,10 +262,50 @@ static void HitInfo_SetFaceNormal(HitInfo* hit, const Ray* ray, vec3 outwardNorm
 }
 
 // ---- scene view over the flattened pools ----
+// Checker for the GPU's subtree-box culling (NOT part of the reference): when `boxes` is
+// set, CheckHitNextNode skips a node whose box the segment [0, kt*tMax] of the ray misses — with the
+// device's own boxes (rtx_scene_cull_data) and the device's own test, operation for operation.
+struct Cull {
+    const float* boxes; // 6 floats per node: min xyz, max xyz
+    vec3         c;
+    f32          ro2, kt;
+    // per ray
+    bool ok;
+    vec3 inv;
+};
+
 struct Scene {
     const rtx_scene_desc* d;
     u64                   nInner, nLeaf, nPrim; // visit counters (per thread copy)
+    Cull*                 cull;
+    u64                   nCulled;
 };
+
+static void cull_begin_ray(Cull* c, const Ray* ray)
+{
+    const f32 big = 3.0e38f;
+    vec3      inv = ray->cache.invDir;
+    inv.x = fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x;
+    inv.y = fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y;
+    inv.z = fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z;
+    c->inv = inv;
+    const f32 rx = ray->origin.x - c->c.x, ry = ray->origin.y - c->c.y, rz = ray->origin.z - c->c.z;
+    const f32 r2 = rx * rx + ry * ry + rz * rz;
+    const f32 d2 = ray->dir.x * ray->dir.x + ray->dir.y * ray->dir.y + ray->dir.z * ray->dir.z;
+    c->ok        = r2 <= c->ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
+}
+
+static bool cull_node(const Cull* c, u32 node, const Ray* ray, f32 tMax)
+{
+    const float* b   = c->boxes + 6ull * node;
+    const vec3   o   = ray->origin;
+    const f32    t1x = (b[0] - o.x) * c->inv.x, t2x = (b[3] - o.x) * c->inv.x;
+    const f32    t1y = (b[1] - o.y) * c->inv.y, t2y = (b[4] - o.y) * c->inv.y;
+    const f32    t1z = (b[2] - o.z) * c->inv.z, t2z = (b[5] - o.z) * c->inv.z;
+    const f32    tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    const f32    tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
+    return c->ok && tn > tf;
+}
 
 struct Prim { // what the reference calls Object*: a pool reference
     u32 ref;  // leaf_ref encoding, or 0xC0000000|i for planes, 0xFFFFFFFF none
@@ -476,6 +516,10 @@ static bool CheckHitInternalNode(Scene* sc, u32 node, const Ray* ray, Prim* objH
 
 static bool CheckHitNextNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, HitInfo* hit, f32 tMax) // :458
 {
+    if (sc->cull && cull_node(sc->cull, node, ray, tMax)) { // checker mode only, see struct Cull
+        sc->nCulled++;
+        return false;
+    }
     u32 type = sc->d->node_w1[node] >> 30;
     if (type == 3u) return CheckHitLeafNode(sc, node, ray, objHit, hit, tMax);
     return CheckHitInternalNode(sc, node, ray, objHit, hit, (int)type, tMax);
@@ -1108,12 +1152,28 @@ static inline uint8_t LinearTosRGB(f32 channel)
 extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o, const float* dxyz, int unit_dir, uint32_t* pid, float* t,
                             float* pos, float* nrm, float* uv, uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
-    Scene sc = {desc, 0, 0, 0};
+    return oracle_trace_culled(desc, NULL, NULL, n, o, dxyz, unit_dir, pid, t, pos, nrm, uv, front, visits3, steps_per_ray);
+}
+
+extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const float* boxes6, const float* info5, size_t n, const float* o,
+                                   const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
+                                   uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
+{
+    Scene sc = {desc, 0, 0, 0, NULL, 0};
+    Cull  cull;
+    if (boxes6) {
+        cull.boxes = boxes6;
+        cull.c     = vec(info5[0], info5[1], info5[2]);
+        cull.ro2   = info5[3];
+        cull.kt    = info5[4];
+        sc.cull    = &cull;
+    }
     for (size_t i = 0; i < n; i++) {
-        const u64 before = sc.nInner + sc.nLeaf + sc.nPrim;
+        const u64 before = sc.nInner + sc.nLeaf + sc.nPrim + sc.nCulled;
         vec3 org = vec(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
         vec3 dir = vec(dxyz[3 * i], dxyz[3 * i + 1], dxyz[3 * i + 2]);
         Ray  ray = unit_dir ? Ray_FromUnit(org, dir) : Ray_Make(org, dir);
+        if (sc.cull) cull_begin_ray(&cull, &ray);
         Prim    obj = {0xFFFFFFFFu};
         HitInfo hit;
         memset(&hit, 0, sizeof hit);
@@ -1125,9 +1185,12 @@ extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o
         if (nrm) nrm[3 * i] = hit.unitNormal.x, nrm[3 * i + 1] = hit.unitNormal.y, nrm[3 * i + 2] = hit.unitNormal.z;
         if (uv) uv[2 * i] = hit.uv.x, uv[2 * i + 1] = hit.uv.y;
         if (front) front[i] = h && hit.frontFace ? 1 : 0;
-        if (steps_per_ray) steps_per_ray[i] = (u32)(sc.nInner + sc.nLeaf + sc.nPrim - before);
+        if (steps_per_ray) steps_per_ray[i] = (u32)(sc.nInner + sc.nLeaf + sc.nPrim + sc.nCulled - before);
     }
-    if (visits3) visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
+    if (visits3) {
+        visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
+        if (boxes6) visits3[3] = sc.nCulled; // 4 counters in checker mode
+    }
     return 0;
 }
 

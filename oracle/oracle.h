@@ -28,6 +28,14 @@ int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* origin_xyz, 
                  uint32_t* prim_id, float* t, float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face,
                  uint64_t* visits3, uint32_t* steps_per_ray /* inner+leaf+prim visits of each ray, or NULL */);
 
+/* The same query with the GPU library's subtree-box culling replayed on the CPU (checker for DESIGN.md §5;
+ * not part of the reference): boxes6 / info5 come from rtx_scene_cull_data.  visits receives 4 counters
+ * {inner, leaf, prim, culled}.  boxes6 == NULL: plain oracle_trace. */
+int oracle_trace_culled(const rtx_scene_desc* desc, const float* boxes6, const float* info5, size_t n,
+                        const float* origin_xyz, const float* dir_xyz, int unit_dir, uint32_t* prim_id, float* t,
+                        float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face, uint64_t* visits,
+                        uint32_t* steps_per_ray);
+
 /* Seeded RenderPixel over the frame partition described by params (same meaning as rtx_render).
  * cum_out: W*H*3 f32 sums (rows not assigned are left untouched); bgr_out: W*H*3 u8 or NULL.
  * rays_at_depth: RTX_MAX_DEPTH counters or NULL.  n_threads <= 0: one thread. */

@@ -13,6 +13,7 @@
 // RTX_E_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,14 +70,14 @@ struct rtx_scene {
     std::vector<void*> allocs;
     uint64_t           bytes;
     // per-scene scratch reused across calls
-    uint64_t* d_counters; // [0..2] visits, [3] queue count, [4] shaded hits
+    uint64_t* d_counters; // [0..3] visits (inner, leaf, prim, culled), [4] shaded hits, [6] queue count, [8] work counter
     hipEvent_t ev[2 * 1024];
     int        n_ev;
     // render workspace (path queues, hit records, per-path results): grown on demand, kept between
     // frames so that a render loop does not pay hipMalloc/hipFree of gigabytes per frame
     void*    ws;
     uint64_t ws_bytes;
-    unsigned persist_blocks[2]; // resident grid of k_trace_persist<false/true> (0 = not queried yet)
+    unsigned persist_blocks[4]; // resident grid of the persistent kernels: [count + 2 * culled] (0 = not queried yet)
 };
 
 static int workspace(rtx_scene* sc, uint64_t bytes, char** out)
@@ -177,6 +178,148 @@ static int validate_desc(const rtx_scene_desc* d)
     return RTX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conservative subtree boxes for the culled closest-hit kernel.
+//
+// The kernel may skip a kd node when the segment {o + t d, 0 <= t <= kt * tMax} misses the node's box.
+// That is safe when the box contains, for every primitive referenced below the node, every point of a
+// ray at which the REFERENCE's binary32 intersection routine could still report a hit, plus the slack of
+// the box test's own arithmetic.  With eps = 2^-24, rays with |d| = 1 (+-1e-3) whose origin lies within
+// D of every vertex, E = max(|e1|, |e2|) and the determinant cut-off |a| >= alpha = 1e-4
+// (Triangle_HitAt, surfaces.c:135-177), standard forward error analysis of
+//     h = d x e2, a = e1.h, s = o - v0, u = (s.h)/a, q = s x e1, v = (d.q)/a, t = (e2.q)/a
+// gives |a - a*| <= 7 eps E^2, |u - u*|, |v - v*| <= (9 eps D E + |u*| 7 eps E^2)/alpha + eps and
+// |t - t*| <= (9 eps D E^2 + |t*| 7 eps E^2)/alpha + eps |t|   (x* = exact value).  So an accepted hit
+// (u, v >= 0, u + v <= 1, 1e-4 <= t <= tMax) has its exact plane point v0 + u* e1 + v* e2 inside the
+// triangle's bounds widened per axis by 4 beta ext_axis, at an exact ray parameter in
+// [-tau, tMax (1 + kappa') + tau]; a point within tau of the tested segment lies in the box widened by
+// tau.  Spheres (Sphere_HitAt, surfaces.c:55-87): the discriminant is off by at most
+// Delta = 24 eps (D^2 + r^2), so a reported root is within 2 sqrt(Delta) + 5 eps D of an exact point of
+// the sphere or of the ray's closest approach, which is then within sqrt(Delta) of the sphere.
+// All bounds are doubled; a triangle whose kappa = 7 eps E^2 / alpha reaches 1/4 (edges over ~7.7 units)
+// gets an unbounded box, i.e. is never culled.  The box test itself computes (b - o) * (1/d) in binary32:
+// its rounding equals a displacement of the box plane by <= 3 eps |b - o| <= 6 eps D, covered by 32 eps D.
+// ---------------------------------------------------------------------------------------------
+struct CullData {
+    std::vector<uint4> nodes32;
+    float              c[3], ro2, kt;
+};
+
+static float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
+static float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
+
+static void build_cull_data(const rtx_scene_desc* d, CullData& out)
+{
+    const double EPS = 5.9604644775390625e-8, ALPHA = 1e-4;
+    const size_t T = d->n_tris, Sn = d->n_spheres, N = d->n_nodes;
+    // scene bounds -> centre, radius; rays are culled only while their origin is within RO of the centre
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < T; i++)
+        for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+                double x = d->tri_pos[(3 * v + a) * T + i];
+                lo[a] = std::min(lo[a], x), hi[a] = std::max(hi[a], x);
+            }
+    for (size_t i = 0; i < Sn; i++)
+        for (int a = 0; a < 3; a++) {
+            double x = d->sph[a * Sn + i], r = fabs((double)d->sph[3 * Sn + i]);
+            lo[a] = std::min(lo[a], x - r), hi[a] = std::max(hi[a], x + r);
+        }
+    double c[3], R = 0.0;
+    for (int a = 0; a < 3; a++) c[a] = 0.5 * (lo[a] + hi[a]), R += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+    R               = sqrt(R) + 1e-6;
+    const double RO = 4.0 * R, D = 1.01 * (RO + R);
+    for (int a = 0; a < 3; a++) out.c[a] = (float)c[a];
+    out.ro2 = round_down(RO * RO * 0.999);
+
+    std::vector<double> plo(3 * (T + Sn)), phi(3 * (T + Sn)); // padded primitive bounds
+    double              kappa_scene = 0.0;
+    for (size_t i = 0; i < T; i++) {
+        float p[9];
+        for (int k = 0; k < 9; k++) p[k] = d->tri_pos[k * T + i];
+        const float  e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+        const double E     = std::max(sqrt((double)e1[0] * e1[0] + (double)e1[1] * e1[1] + (double)e1[2] * e1[2]),
+                                      sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]));
+        const double kappa = 7.0 * EPS * E * E / ALPHA;
+        const bool   finite = std::isfinite(E) && kappa < 0.25;
+        const double beta  = finite ? 2.0 * ((9.0 * EPS * D * E / ALPHA + kappa + EPS) / (1.0 - kappa)) : 0.0;
+        const double tau   = finite ? 2.0 * (9.0 * EPS * D * E * E / ALPHA) / (1.0 - kappa) : 0.0;
+        if (finite) kappa_scene = std::max(kappa_scene, 2.0 * (kappa + 2.0 * EPS) / (1.0 - kappa));
+        for (int a = 0; a < 3; a++) {
+            // bounds over v0, v1, v2 and v0 + e1, v0 + e2 as the kernel's records hold them
+            double x0 = p[a], x1 = p[3 + a], x2 = p[6 + a], y1 = (double)p[a] + e1[a], y2 = (double)p[a] + e2[a];
+            double mn = std::min({x0, x1, x2, y1, y2}), mx = std::max({x0, x1, x2, y1, y2});
+            double pad = 4.0 * beta * (mx - mn) + tau + 32.0 * EPS * D;
+            plo[3 * i + a] = finite ? mn - pad : -INFINITY;
+            phi[3 * i + a] = finite ? mx + pad : INFINITY;
+        }
+    }
+    for (size_t i = 0; i < Sn; i++) {
+        const double r = fabs((double)d->sph[3 * Sn + i]), Delta = 24.0 * EPS * (D * D + r * r);
+        const double pad = 2.0 * (3.0 * sqrt(Delta) + 5.0 * EPS * D) + 32.0 * EPS * D;
+        for (int a = 0; a < 3; a++) {
+            plo[3 * (T + i) + a] = (double)d->sph[a * Sn + i] - r - pad;
+            phi[3 * (T + i) + a] = (double)d->sph[a * Sn + i] + r + pad;
+        }
+    }
+    out.kt = round_up(1.0 + kappa_scene + 64.0 * EPS);
+
+    // subtree boxes, children before parents (explicit stack: the tree can be 60 levels deep but is not balanced)
+    std::vector<double>   blo(3 * N, INFINITY), bhi(3 * N, -INFINITY);
+    std::vector<uint32_t> order, st;
+    order.reserve(N);
+    st.push_back(d->root_index);
+    while (!st.empty()) {
+        uint32_t n = st.back();
+        st.pop_back();
+        order.push_back(n);
+        if ((d->node_w1[n] >> 30) != 3u) st.push_back(n + 1), st.push_back(d->node_w1[n] & 0x3FFFFFFFu);
+    }
+    for (size_t k = order.size(); k-- > 0;) {
+        const uint32_t n = order[k];
+        if ((d->node_w1[n] >> 30) == 3u) {
+            const uint32_t len = d->node_w0[n], first = d->node_w1[n] & 0x3FFFFFFFu;
+            for (uint32_t j = 0; j < len; j++) {
+                const uint32_t r = d->leaf_ref[first + j];
+                const size_t   p = (r & RTX_REF_SPHERE) ? T + (r & 0x7FFFFFFFu) : r;
+                for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * n + a], plo[3 * p + a]), bhi[3 * n + a] = std::max(bhi[3 * n + a], phi[3 * p + a]);
+            }
+        } else {
+            const uint32_t l = d->node_w1[n] & 0x3FFFFFFFu, r = n + 1;
+            for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * l + a], blo[3 * r + a]), bhi[3 * n + a] = std::max(bhi[3 * l + a], bhi[3 * r + a]);
+        }
+    }
+    out.nodes32.resize(2 * N);
+    for (size_t n = 0; n < N; n++) {
+        float b[6];
+        for (int a = 0; a < 3; a++) {
+            const bool empty = !(blo[3 * n + a] <= bhi[3 * n + a]); // node never reached from the root, or an empty leaf (handled by its len == 0)
+            b[a]     = empty ? 0.0f : std::max(round_down(blo[3 * n + a]), -3.0e38f);
+            b[3 + a] = empty ? 0.0f : std::min(round_up(bhi[3 * n + a]), 3.0e38f);
+        }
+        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        out.nodes32[2 * n + 0] = make_uint4(d->node_w0[n], d->node_w1[n], bits(b[0]), bits(b[1]));
+        out.nodes32[2 * n + 1] = make_uint4(bits(b[2]), bits(b[3]), bits(b[4]), bits(b[5]));
+    }
+}
+
+extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, float* boxes6, float* info5)
+{
+    if (!boxes6 || !info5) return fail(RTX_E_INVALID, "null argument");
+    int rc = validate_desc(d);
+    if (rc != RTX_OK) return rc;
+    CullData cd;
+    build_cull_data(d, cd);
+    for (size_t n = 0; n < d->n_nodes; n++) {
+        const uint32_t w[6] = {cd.nodes32[2 * n].z, cd.nodes32[2 * n].w, cd.nodes32[2 * n + 1].x, cd.nodes32[2 * n + 1].y, cd.nodes32[2 * n + 1].z, cd.nodes32[2 * n + 1].w};
+        memcpy(boxes6 + 6 * n, w, sizeof w);
+    }
+    for (int a = 0; a < 3; a++) info5[a] = cd.c[a];
+    info5[3] = cd.ro2;
+    info5[4] = cd.kt;
+    return RTX_OK;
+}
+
 extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene** out)
 {
     if (!out) return fail(RTX_E_INVALID, "null output");
@@ -193,7 +336,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     sc->n_ev      = 0;
     sc->ws        = nullptr;
     sc->ws_bytes  = 0;
-    sc->persist_blocks[0] = sc->persist_blocks[1] = 0;
+    memset(sc->persist_blocks, 0, sizeof sc->persist_blocks);
     memset(&sc->dev, 0, sizeof sc->dev);
     SceneDev& S = sc->dev;
 
@@ -206,6 +349,14 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         std::vector<uint2> nodes(d->n_nodes);
         for (uint32_t i = 0; i < d->n_nodes; i++) nodes[i] = make_uint2(d->node_w0[i], d->node_w1[i]);
         UP(upload(sc, nodes.data(), nodes.size(), &S.nodes));
+    }
+    {
+        CullData cd;
+        build_cull_data(d, cd);
+        UP(upload(sc, cd.nodes32.data(), cd.nodes32.size(), &S.nodes32));
+        for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a];
+        S.cull_ro2 = cd.ro2;
+        S.cull_kt  = cd.kt;
     }
     {
         // Device-side triangle order = order of first appearance in the leaf reference stream (the
@@ -384,16 +535,18 @@ __global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uin
 DEV void add_visits(uint64_t* counters, const Visits& v)
 {
     // wave reduction, one atomic per wave and counter
-    uint32_t a = v.inner, b = v.leaf, c = v.prim;
+    uint32_t a = v.inner, b = v.leaf, c = v.prim, e = v.culled;
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_down(a, off);
         b += __shfl_down(b, off);
         c += __shfl_down(c, off);
+        e += __shfl_down(e, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long*)&counters[0], (unsigned long long)a);
         atomicAdd((unsigned long long*)&counters[1], (unsigned long long)b);
         atomicAdd((unsigned long long*)&counters[2], (unsigned long long)c);
+        atomicAdd((unsigned long long*)&counters[3], (unsigned long long)e);
     }
 }
 
@@ -645,7 +798,7 @@ enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2 };
 #define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave
 #endif
 
-template <bool COUNT>
+template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
                                                     uint32_t chunk, uint64_t* counters)
@@ -673,7 +826,8 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     uint32_t leafPos = 0, leafEnd = 0, curRef = 0;
     float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
     uint32_t best = HIT_MISS;
-    Visits   vis  = {0, 0, 0};
+    bool     cullOK = false; // this lane's ray meets the preconditions of the box bounds
+    Visits   vis  = {0, 0, 0, 0};
 
     for (;;) {
         const uint64_t idle  = __ballot(state == ST_IDLE);
@@ -701,6 +855,18 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     d    = mk3(rays[3 * stride + ridx], rays[4 * stride + ridx], rays[5 * stride + ridx]);
                     inv  = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13)
                     odd  = vdivc(o, d);
+                    if (CULL) {
+                        // 1/0 = inf would turn (b - o) * inv into NaN when b == o.  The literal walk never uses
+                        // inv on an axis with |d| < 1e-4 (kdtree.c:509-516), so the box test's own finite stand-in
+                        // can live in the same register.
+                        const float big = 3.0e38f;
+                        inv.x = fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x;
+                        inv.y = fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y;
+                        inv.z = fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z;
+                        const float rx = o.x - S.cull_c[0], ry = o.y - S.cull_c[1], rz = o.z - S.cull_c[2];
+                        const float r2 = rx * rx + ry * ry + rz * rz, d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                        cullOK         = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f; // false for any NaN / inf component
+                    }
                     asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
                     node  = S.root;
                     tMax  = RTX_INF;
@@ -715,10 +881,27 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
 
         bool pop = false, fin = false;
         if (state == ST_INNER) {
-            const uint2    nd   = S.nodes[node];
+            uint2 nd;
+            bool  culled = false;
+            if (CULL) {
+                const uint4 q0 = S.nodes32[2ull * node], q1 = S.nodes32[2ull * node + 1];
+                nd             = make_uint2(q0.x, q0.y);
+                // slab test of the segment [0, kt * tMax] against the subtree's conservative box
+                const float t1x = (__uint_as_float(q0.z) - o.x) * inv.x, t2x = (__uint_as_float(q1.y) - o.x) * inv.x;
+                const float t1y = (__uint_as_float(q0.w) - o.y) * inv.y, t2y = (__uint_as_float(q1.z) - o.y) * inv.y;
+                const float t1z = (__uint_as_float(q1.x) - o.z) * inv.z, t2z = (__uint_as_float(q1.w) - o.z) * inv.z;
+                const float tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+                const float tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * S.cull_kt));
+                culled          = cullOK && tn > tf;
+            } else {
+                nd = S.nodes[node];
+            }
             const uint32_t type = nd.y >> 30;
             const uint32_t idx  = nd.y & 0x3FFFFFFFu;
-            if (type == 3u) {
+            if (culled) {
+                if (COUNT) vis.culled++;
+                pop = true; // nothing below this node can report a hit for this ray
+            } else if (type == 3u) {
                 if (COUNT) vis.leaf++;
                 if (nd.x != 0u) {
                     state   = ST_LEAF;
@@ -944,36 +1127,39 @@ __global__ __launch_bounds__(256) void k_tonemap(const float* __restrict__ accum
 }
 
 // ---- parity-seam kernels (small batches) ----
-template <bool COUNT>
-__global__ __launch_bounds__(64) void k_trace_full(SceneDev S, const float* __restrict__ o_xyz, const float* __restrict__ d_xyz, uint64_t n,
-                                                   uint32_t* prim_id, float* t_out, float* pos, float* nrm, float* uv, uint8_t* front,
-                                                   uint64_t* counters, int unit_dir)
+// rtx_trace_closest = k_prep_rays → the SAME closest-hit kernel the renderer launches → k_expand_hits
+__global__ void k_prep_rays(const float* __restrict__ o_xyz, const float* __restrict__ d_xyz, uint64_t n, float* __restrict__ rays, int unit_dir)
 {
-    uint64_t i   = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Visits   vis = {0, 0, 0};
-    if (i < n) {
-        f3       o = mk3(o_xyz[3 * i], o_xyz[3 * i + 1], o_xyz[3 * i + 2]);
-        f3       d = mk3(d_xyz[3 * i], d_xyz[3 * i + 1], d_xyz[3 * i + 2]);
-        if (!unit_dir) d = vnorm(d); // Ray_Make
-        RayD     r = ray_from_unit(o, d);
-        uint32_t ref;
-        float    t, u, v;
-        closest_hit<COUNT>(S, r, ref, t, u, v, vis);
-        if (prim_id) prim_id[i] = hit_prim_id(S, ref);
-        HitD h;
-        if (ref != HIT_MISS) {
-            h = make_hitinfo(S, o, d, ref, t, u, v);
-        } else {
-            h.pos = mk3(0, 0, 0), h.n = mk3(0, 0, 0), h.u = 0, h.v = 0, h.front = false, h.mat = 0;
-            t = 0.0f;
-        }
-        if (t_out) t_out[i] = t;
-        if (pos) pos[3 * i] = h.pos.x, pos[3 * i + 1] = h.pos.y, pos[3 * i + 2] = h.pos.z;
-        if (nrm) nrm[3 * i] = h.n.x, nrm[3 * i + 1] = h.n.y, nrm[3 * i + 2] = h.n.z;
-        if (uv) uv[2 * i] = h.u, uv[2 * i + 1] = h.v;
-        if (front) front[i] = h.front ? 1 : 0;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 d = mk3(d_xyz[3 * i], d_xyz[3 * i + 1], d_xyz[3 * i + 2]);
+    if (!unit_dir) d = vnorm(d); // Ray_Make
+    rays[0 * n + i] = o_xyz[3 * i], rays[1 * n + i] = o_xyz[3 * i + 1], rays[2 * n + i] = o_xyz[3 * i + 2];
+    rays[3 * n + i] = d.x, rays[4 * n + i] = d.y, rays[5 * n + i] = d.z;
+}
+
+__global__ void k_expand_hits(SceneDev S, const float* __restrict__ rays, const uint32_t* __restrict__ hits, uint64_t n, uint32_t* prim_id,
+                              float* t_out, float* pos, float* nrm, float* uv, uint8_t* front)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3       o   = mk3(rays[0 * n + i], rays[1 * n + i], rays[2 * n + i]);
+    const f3       d   = mk3(rays[3 * n + i], rays[4 * n + i], rays[5 * n + i]);
+    const uint32_t ref = hits[0 * n + i];
+    float          t = __uint_as_float(hits[1 * n + i]), u = __uint_as_float(hits[2 * n + i]), v = __uint_as_float(hits[3 * n + i]);
+    if (prim_id) prim_id[i] = hit_prim_id(S, ref);
+    HitD h;
+    if (ref != HIT_MISS) {
+        h = make_hitinfo(S, o, d, ref, t, u, v);
+    } else {
+        h.pos = mk3(0, 0, 0), h.n = mk3(0, 0, 0), h.u = 0, h.v = 0, h.front = false, h.mat = 0;
+        t = 0.0f;
     }
-    if (COUNT) add_visits(counters, vis);
+    if (t_out) t_out[i] = t;
+    if (pos) pos[3 * i] = h.pos.x, pos[3 * i + 1] = h.pos.y, pos[3 * i + 2] = h.pos.z;
+    if (nrm) nrm[3 * i] = h.n.x, nrm[3 * i + 1] = h.n.y, nrm[3 * i + 2] = h.n.z;
+    if (uv) uv[2 * i] = h.u, uv[2 * i + 1] = h.v;
+    if (front) front[i] = h.front ? 1 : 0;
 }
 
 __global__ void k_camera_rays(rtx_camera cam, FrameGeom g, uint64_t n, const uint32_t* pixel_index, const uint32_t* sample, float* o_xyz,
@@ -1046,18 +1232,21 @@ static int trace_variant()
 {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("RTX_TRACE_VARIANT"); // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine
-        v             = e ? atoi(e) : 2;
+        // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine,
+        // 3: 2 + subtree-box culling (default).  0..2 walk the tree literally.
+        const char* e = getenv("RTX_TRACE_VARIANT");
+        v             = e ? atoi(e) : 3;
     }
     return v;
 }
 
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
-                        bool count, uint64_t* d_counters)
+                        bool count, uint64_t* d_counters, bool literal)
 {
     if (n == 0) return RTX_OK;
     if (n > (uint64_t)0x7FFFFFFF * 64) return fail(RTX_E_LIMIT, "too many rays for one launch");
-    if (trace_variant() == 0) {
+    const int variant = literal ? std::min(trace_variant(), 2) : trace_variant();
+    if (variant == 0) {
         unsigned nb = blocks_for(n, 64);
         if (count) {
             hipLaunchKernelGGL(k_trace<true>, dim3(nb), dim3(64), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, d_counters);
@@ -1070,19 +1259,21 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     // persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
     // that would not fit simply start later and find the queue empty — nothing waits on another block)
     typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*);
-    const int     variant = trace_variant();
-    PersistKernel kern    = variant == 1 ? (count ? k_trace_persist<true> : k_trace_persist<false>) : (count ? k_trace_flat<true> : k_trace_flat<false>);
-    if (sc->persist_blocks[count ? 1 : 0] == 0) {
+    PersistKernel kern    = variant == 1   ? (count ? k_trace_persist<true> : k_trace_persist<false>)
+                            : variant == 2 ? (count ? k_trace_flat<true, false> : k_trace_flat<false, false>)
+                                           : (count ? k_trace_flat<true, true> : k_trace_flat<false, true>);
+    const int     slot    = (count ? 1 : 0) + (variant >= 3 ? 2 : 0);
+    if (sc->persist_blocks[slot] == 0) {
         int per_cu = 0, cus = 0;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        sc->persist_blocks[count ? 1 : 0] = (unsigned)(per_cu * cus);
+        sc->persist_blocks[slot] = (unsigned)(per_cu * cus);
     }
     unsigned long long* work = (unsigned long long*)&sc->d_counters[8];
     HIPCHECK(hipMemsetAsync(work, 0, sizeof(unsigned long long), st));
-    const unsigned resident = sc->persist_blocks[count ? 1 : 0];
+    const unsigned resident = sc->persist_blocks[slot];
     const uint64_t waves    = (uint64_t)resident * 4;
     // chunk: about 8 grabs per wave on big queues, never below one wave's worth
     uint64_t chunk = n / (waves * 8);
@@ -1098,9 +1289,9 @@ extern "C" int rtx_trace_closest_device(rtx_scene* sc, size_t n, const float* d_
 {
     if (!sc || (n && (!d_rays || !d_hits))) return fail(RTX_E_INVALID, "null argument");
     bool count = (flags & RTX_RENDER_COUNT_VISITS) != 0;
-    if (count && !d_visit_counters) return fail(RTX_E_INVALID, "COUNT_VISITS needs a counter buffer (3 x u64)");
+    if (count && !d_visit_counters) return fail(RTX_E_INVALID, "COUNT_VISITS needs a counter buffer (4 x u64)");
     HIPCHECK(hipSetDevice(sc->device));
-    return launch_trace(sc, d_rays, n, n, d_hits, n, (hipStream_t)stream, count, d_visit_counters);
+    return launch_trace(sc, d_rays, n, n, d_hits, n, (hipStream_t)stream, count, d_visit_counters, (flags & RTX_TRACE_LITERAL) != 0);
 }
 
 extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xyz, const float* dir_xyz, uint32_t* prim_id, float* t,
@@ -1112,7 +1303,8 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
     bool         count = (flags & RTX_RENDER_COUNT_VISITS) != 0;
     const int    unit_dir = (flags & RTX_TRACE_UNIT_DIR) ? 1 : 0;
     const size_t CH    = 1u << 22;
-    DevBuf       bo, bd, bid, bt, bp, bn, buv, bf;
+    const bool   literal = (flags & RTX_TRACE_LITERAL) != 0;
+    DevBuf       bo, bd, bid, bt, bp, bn, buv, bf, brays, bhits;
     size_t       m = std::min(n, CH);
     HIPCHECK(bo.alloc(m * 12));
     HIPCHECK(bd.alloc(m * 12));
@@ -1122,6 +1314,8 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
     HIPCHECK(bn.alloc(m * 12));
     HIPCHECK(buv.alloc(m * 8));
     HIPCHECK(bf.alloc(m));
+    HIPCHECK(brays.alloc(m * 24));
+    HIPCHECK(bhits.alloc(m * 16));
     HIPCHECK(hipMemset(sc->d_counters, 0, 16 * sizeof(uint64_t)));
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
@@ -1131,16 +1325,15 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
         size_t k = std::min(CH, n - off);
         HIPCHECK(hipMemcpy(bo.p, origin_xyz + 3 * off, k * 12, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(bd.p, dir_xyz + 3 * off, k * 12, hipMemcpyHostToDevice));
-        HIPCHECK(hipEventRecord(e0, 0));
-        if (count) {
-            hipLaunchKernelGGL(k_trace_full<true>, dim3(blocks_for(k, 64)), dim3(64), 0, 0, sc->dev, bo.as<float>(), bd.as<float>(), (uint64_t)k,
-                               bid.as<uint32_t>(), bt.as<float>(), bp.as<float>(), bn.as<float>(), buv.as<float>(), bf.as<uint8_t>(), sc->d_counters, unit_dir);
-        } else {
-            hipLaunchKernelGGL(k_trace_full<false>, dim3(blocks_for(k, 64)), dim3(64), 0, 0, sc->dev, bo.as<float>(), bd.as<float>(), (uint64_t)k,
-                               bid.as<uint32_t>(), bt.as<float>(), bp.as<float>(), bn.as<float>(), buv.as<float>(), bf.as<uint8_t>(), sc->d_counters, unit_dir);
-        }
+        hipLaunchKernelGGL(k_prep_rays, dim3(blocks_for(k, 256)), dim3(256), 0, 0, bo.as<float>(), bd.as<float>(), (uint64_t)k, brays.as<float>(), unit_dir);
         HIPCHECK(hipGetLastError());
+        HIPCHECK(hipEventRecord(e0, 0));
+        int rc = launch_trace(sc, brays.as<float>(), k, k, bhits.as<uint32_t>(), k, 0, count, sc->d_counters, literal);
+        if (rc != RTX_OK) return rc;
         HIPCHECK(hipEventRecord(e1, 0));
+        hipLaunchKernelGGL(k_expand_hits, dim3(blocks_for(k, 256)), dim3(256), 0, 0, sc->dev, brays.as<float>(), bhits.as<uint32_t>(), (uint64_t)k,
+                           bid.as<uint32_t>(), bt.as<float>(), bp.as<float>(), bn.as<float>(), buv.as<float>(), bf.as<uint8_t>());
+        HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventSynchronize(e1));
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -1160,9 +1353,9 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
         stats->ms_trace = stats->ms_total = ms_total;
         stats->trace_launches             = (uint32_t)((n + CH - 1) / CH);
         if (count) {
-            uint64_t c[3];
+            uint64_t c[4];
             HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
-            stats->visits_inner = c[0], stats->visits_leaf = c[1], stats->visits_prim = c[2];
+            stats->visits_inner = c[0], stats->visits_leaf = c[1], stats->visits_prim = c[2], stats->visits_culled = c[3];
         }
     }
     return RTX_OK;
@@ -1222,7 +1415,8 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     hipStream_t st = (hipStream_t)stream;
     rtx_stats   local;
     memset(&local, 0, sizeof local);
-    const bool count = (p->flags & RTX_RENDER_COUNT_VISITS) != 0;
+    const bool count   = (p->flags & RTX_RENDER_COUNT_VISITS) != 0;
+    const bool literal = (p->flags & RTX_TRACE_LITERAL) != 0;
 
     const uint64_t n_pixels = (uint64_t)rows * g.width;
     const uint64_t total    = n_pixels * g.n_samples;
@@ -1245,7 +1439,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     Hits   hits   = {(uint32_t*)(ws + 2 * qbytes), cap};
     float* result = (float*)(ws + 2 * qbytes + cap * 16);
 
-    unsigned long long* d_cnt    = (unsigned long long*)&sc->d_counters[3];
+    unsigned long long* d_cnt    = (unsigned long long*)&sc->d_counters[6];
     unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
     HIPCHECK(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint64_t), st));
 
@@ -1283,7 +1477,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
             local.rays_at_depth[depth] += n;
             local.rays_total += n;
             cur_depth = depth;
-            rc = timed(1, [&] { (void)launch_trace(sc, q[cur].base, cap, n, hits.base, cap, st, count, sc->d_counters); });
+            rc = timed(1, [&] { (void)launch_trace(sc, q[cur].base, cap, n, hits.base, cap, st, count, sc->d_counters, literal); });
             if (rc != RTX_OK) return rc;
             local.trace_launches++;
             HIPCHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
@@ -1318,7 +1512,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     }
     uint64_t c[5];
     HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2];
+    local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2], local.visits_culled = c[3];
     local.hits_shaded  = c[4];
     if (stats) *stats = local;
     return RTX_OK;

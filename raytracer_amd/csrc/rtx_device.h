@@ -29,6 +29,11 @@
 // ---------------------------------------------------------------------------------------------
 struct SceneDev {
     const uint2*    nodes;    // {w0 = split bits | len, w1 = type<<30 | index}
+    // the same nodes with a conservative box of the primitives referenced below each (k_trace_flat<.., CULL>),
+    // 32 B per node:  [0] = w0 w1 min.x min.y   [1] = min.z max.x max.y max.z
+    const uint4*    nodes32;
+    float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
+    float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
     const uint32_t* leaf_ref; // pool bit | pool index
     // hot triangle pool, 48 B per triangle:
     //   [0] = v0.x v0.y v0.z e1.x   [1] = e1.y e1.z e2.x e2.y   [2] = e2.z 0 0 0
@@ -302,6 +307,7 @@ DEV bool Plane_HitAt(f3 n, f3 p, f3 o, f3 d, float tMin, float tMax, float& t) /
 // ---------------------------------------------------------------------------------------------
 struct Visits {
     uint32_t inner, leaf, prim;
+    uint32_t culled; // nodes fetched and skipped by the box test (culled kernel only)
 };
 
 template <bool COUNT>

@@ -12,11 +12,12 @@ from .host import (LIB_DIR, rtx_camera, rtx_render_params, rtx_scene_desc, rtx_s
 RTX_RENDER_COUNT_VISITS = 1
 RTX_RENDER_PIXEL_CENTRES = 2
 RTX_TRACE_UNIT_DIR = 4
+RTX_TRACE_LITERAL = 8
 RTX_ID_MISS = 0xFFFFFFFF
 RTX_ID_UNBOUNDED = 0x80000000
 
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
-           "rtx_scene_device_bytes", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
+           "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
            "rtx_skybox_color"]
 
@@ -50,6 +51,7 @@ def lib() -> C.CDLL:
     sig("rtx_scene_create", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.POINTER(vp))
     sig("rtx_scene_destroy", C.c_int, vp)
     sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
+    sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), f32p, f32p)
     sig("rtx_trace_closest", C.c_int, vp, C.c_size_t, f32p, f32p, u32p, f32p, f32p, f32p, f32p, u8p,
         C.POINTER(rtx_stats), C.c_uint32)
     sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
@@ -102,6 +104,14 @@ def make_params(width, height, spp, max_depth, seed=(1, 2), sample_range=None, b
     p.flags = flags
     p.max_paths_in_flight = max_paths_in_flight
     return p
+
+
+def cull_data(desc):
+    """Conservative subtree boxes + culling constants of a scene (host-side preprocessing, no device needed)."""
+    boxes = np.zeros((desc.contents.n_nodes, 6), np.float32)
+    info = np.zeros(5, np.float32)
+    _check(lib().rtx_cull_data_build(desc, _p(boxes, C.c_float), _p(info, C.c_float)))
+    return boxes, info
 
 
 class DeviceScene:

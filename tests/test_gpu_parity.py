@@ -98,10 +98,28 @@ def test_full_1080p_primary_checksums(built_scenes, device_scenes, scene):
 def test_visit_counters_match_the_oracle(built_scenes, device_scenes):
     """The literal traversal order is reproduced: inner / leaf / primitive visit totals are equal."""
     rec = golden("primary_teapot_B.npz")["rec"]
-    got = device_scenes("teapot").trace_closest(rec["o"], rec["d"], flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_RENDER_COUNT_VISITS)
+    got = device_scenes("teapot").trace_closest(rec["o"], rec["d"],
+                                                flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_RENDER_COUNT_VISITS | hip.RTX_TRACE_LITERAL)
     want = O.trace(built_scenes("teapot").desc, rec["o"], rec["d"], unit_dir=True)["visits"]
     s = got["stats"]
-    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == want.tolist()
+    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == want.tolist() and s["visits_culled"] == 0
+
+
+@pytest.mark.parametrize("scene", ["teapot", "dragon1"])
+def test_culled_walk_replays_on_the_cpu(built_scenes, device_scenes, scene):
+    """Default kernel = literal walk + subtree-box culling.  Same hits as the literal kernel, and the CPU
+    checker that replays the culling with the same boxes visits exactly as many nodes."""
+    rec = golden("primary_%s_B.npz" % scene)["rec"]
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    cul = ds.trace_closest(rec["o"], rec["d"], flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_RENDER_COUNT_VISITS)
+    lit = ds.trace_closest(rec["o"], rec["d"], flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_TRACE_LITERAL)
+    assert np.array_equal(cul["prim_id"], lit["prim_id"]) and np.array_equal(cul["front"], lit["front"])
+    for k in ("t", "position", "normal", "uv"):
+        assert same_bits(cul[k], lit[k]), k
+    want = O.trace(sc.desc, rec["o"], rec["d"], unit_dir=True, cull=hip.cull_data(sc.desc))["visits"]
+    s = cul["stats"]
+    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"], s["visits_culled"]] == want.tolist()
+    assert s["visits_inner"] + s["visits_leaf"] + s["visits_culled"] < 0.5 * len(rec) * 100  # and it does cull
 
 
 def test_material_bounce_vs_reference(built_scenes, device_scenes):
