@@ -262,16 +262,17 @@ static void HitInfo_SetFaceNormal(HitInfo* hit, const Ray* ray, vec3 outwardNorm
 }
 
 // ---- scene view over the flattened pools ----
-// Checker for the GPU's subtree-box culling (NOT part of the reference): when `boxes` is
+// Checker for the GPU's subtree-box culling (NOT part of the reference): when `qbox` is
 // set, CheckHitNextNode skips a node whose box the segment [0, kt*tMax] of the ray misses — with the
 // device's own boxes (rtx_scene_cull_data) and the device's own test, operation for operation.
 struct Cull {
-    const float* boxes; // 6 floats per node: min xyz, max xyz
-    vec3         c;
-    f32          ro2, kt;
+    const uint32_t* qbox; // 2 words per node: qmin, qmax (x | y << 11 | z << 22); qmin = 0xFFFFFFFF: never cull
+    vec3            c;
+    f32             ro2, kt;
+    vec3            lo, scale, iscale;
     // per ray
     bool ok;
-    vec3 inv;
+    vec3 o, inv; // origin, and 1/dir with infinities replaced by +-3e38
 };
 
 struct Scene {
@@ -283,28 +284,29 @@ struct Scene {
 
 static void cull_begin_ray(Cull* c, const Ray* ray)
 {
-    const f32 big = 3.0e38f;
-    vec3      inv = ray->cache.invDir;
-    inv.x = fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x;
-    inv.y = fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y;
-    inv.z = fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z;
-    c->inv = inv;
-    const f32 rx = ray->origin.x - c->c.x, ry = ray->origin.y - c->c.y, rz = ray->origin.z - c->c.z;
+    const f32  big = 3.0e38f;
+    const vec3 o = ray->origin, inv = ray->cache.invDir;
+    c->inv = vec(fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x, fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y,
+                 fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z);
+    c->o   = o;
+    const f32 rx = o.x - c->c.x, ry = o.y - c->c.y, rz = o.z - c->c.z;
     const f32 r2 = rx * rx + ry * ry + rz * rz;
     const f32 d2 = ray->dir.x * ray->dir.x + ray->dir.y * ray->dir.y + ray->dir.z * ray->dir.z;
     c->ok        = r2 <= c->ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
 }
 
-static bool cull_node(const Cull* c, u32 node, const Ray* ray, f32 tMax)
+static bool cull_node(const Cull* c, u32 node, f32 tMax)
 {
-    const float* b   = c->boxes + 6ull * node;
-    const vec3   o   = ray->origin;
-    const f32    t1x = (b[0] - o.x) * c->inv.x, t2x = (b[3] - o.x) * c->inv.x;
-    const f32    t1y = (b[1] - o.y) * c->inv.y, t2y = (b[4] - o.y) * c->inv.y;
-    const f32    t1z = (b[2] - o.z) * c->inv.z, t2z = (b[5] - o.z) * c->inv.z;
-    const f32    tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
-    const f32    tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
-    return c->ok && tn > tf;
+    const u32 qz = c->qbox[2ull * node], qw = c->qbox[2ull * node + 1];
+    const f32 bx0 = fmaf((f32)(qz & 0x7FFu), c->scale.x, c->lo.x), bx1 = fmaf((f32)(qw & 0x7FFu), c->scale.x, c->lo.x);
+    const f32 by0 = fmaf((f32)((qz >> 11) & 0x7FFu), c->scale.y, c->lo.y), by1 = fmaf((f32)((qw >> 11) & 0x7FFu), c->scale.y, c->lo.y);
+    const f32 bz0 = fmaf((f32)(qz >> 22), c->scale.z, c->lo.z), bz1 = fmaf((f32)(qw >> 22), c->scale.z, c->lo.z);
+    const f32 t1x = (bx0 - c->o.x) * c->inv.x, t2x = (bx1 - c->o.x) * c->inv.x;
+    const f32 t1y = (by0 - c->o.y) * c->inv.y, t2y = (by1 - c->o.y) * c->inv.y;
+    const f32 t1z = (bz0 - c->o.z) * c->inv.z, t2z = (bz1 - c->o.z) * c->inv.z;
+    const f32 tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    const f32 tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
+    return c->ok && qz != 0xFFFFFFFFu && tn > tf;
 }
 
 struct Prim { // what the reference calls Object*: a pool reference
@@ -516,7 +518,7 @@ static bool CheckHitInternalNode(Scene* sc, u32 node, const Ray* ray, Prim* objH
 
 static bool CheckHitNextNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, HitInfo* hit, f32 tMax) // :458
 {
-    if (sc->cull && cull_node(sc->cull, node, ray, tMax)) { // checker mode only, see struct Cull
+    if (sc->cull && cull_node(sc->cull, node, tMax)) { // checker mode only, see struct Cull
         sc->nCulled++;
         return false;
     }
@@ -1155,18 +1157,21 @@ extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o
     return oracle_trace_culled(desc, NULL, NULL, n, o, dxyz, unit_dir, pid, t, pos, nrm, uv, front, visits3, steps_per_ray);
 }
 
-extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const float* boxes6, const float* info5, size_t n, const float* o,
+extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint32_t* qbox2, const float* info14, size_t n, const float* o,
                                    const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
                                    uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
     Scene sc = {desc, 0, 0, 0, NULL, 0};
     Cull  cull;
-    if (boxes6) {
-        cull.boxes = boxes6;
-        cull.c     = vec(info5[0], info5[1], info5[2]);
-        cull.ro2   = info5[3];
-        cull.kt    = info5[4];
-        sc.cull    = &cull;
+    if (qbox2) {
+        cull.qbox   = qbox2;
+        cull.c      = vec(info14[0], info14[1], info14[2]);
+        cull.ro2    = info14[3];
+        cull.kt     = info14[4];
+        cull.lo     = vec(info14[5], info14[6], info14[7]);
+        cull.scale  = vec(info14[8], info14[9], info14[10]);
+        cull.iscale = vec(info14[11], info14[12], info14[13]);
+        sc.cull     = &cull;
     }
     for (size_t i = 0; i < n; i++) {
         const u64 before = sc.nInner + sc.nLeaf + sc.nPrim + sc.nCulled;
@@ -1189,7 +1194,7 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const float* boxe
     }
     if (visits3) {
         visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
-        if (boxes6) visits3[3] = sc.nCulled; // 4 counters in checker mode
+        if (qbox2) visits3[3] = sc.nCulled; // 4 counters in checker mode
     }
     return 0;
 }

@@ -29,11 +29,13 @@
 // ---------------------------------------------------------------------------------------------
 struct SceneDev {
     const uint2*    nodes;    // {w0 = split bits | len, w1 = type<<30 | index}
-    // the same nodes with a conservative box of the primitives referenced below each (k_trace_flat<.., CULL>),
-    // 32 B per node:  [0] = w0 w1 min.x min.y   [1] = min.z max.x max.y max.z
-    const uint4*    nodes32;
+    // the same nodes with a conservative, quantised box of the primitives referenced below each
+    // (k_trace_flat<.., CULL>), 16 B per node:  {w0, w1, qmin, qmax},  q = x | y << 11 | z << 22 on the grid
+    // cull_lo + q * cull_scale (2047 x 2047 x 1023 steps); qmin = 0xFFFFFFFF: never cull this node
+    const uint4*    nodes16;
     float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
+    float           cull_lo[3], cull_scale[3], cull_iscale[3];
     const uint32_t* leaf_ref; // pool bit | pool index
     // hot triangle pool, 48 B per triangle:
     //   [0] = v0.x v0.y v0.z e1.x   [1] = e1.y e1.z e2.x e2.y   [2] = e2.z 0 0 0

@@ -40,12 +40,14 @@ def test_culled_equals_literal_on_golden_rays(built_scenes, scene):
 
 def test_culled_equals_literal_on_awkward_rays(built_scenes):
     sc = built_scenes("teapot")
-    boxes, info = hip.cull_data(sc.desc)
+    cull = hip.cull_data(sc.desc)
+    info = cull[1]
+    boxes = hip.cull_boxes_world(*cull).astype(np.float32)
     rng = np.random.default_rng(7)
     n = 20000
     node = rng.integers(0, len(boxes), n)
     lo, hi = boxes[node, :3], boxes[node, 3:]
-    inside = lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)
+    inside = (lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)).astype(np.float32)
     o = inside.copy()
     face = rng.integers(0, 6, n)
     for a in range(3):  # origins exactly on a face of some node's box
@@ -59,20 +61,20 @@ def test_culled_equals_literal_on_awkward_rays(built_scenes):
     axis = rng.integers(0, 3, n // 10)  # and some exactly along an axis
     d[: n // 10] = 0.0
     d[np.arange(n // 10), axis] = np.where(rng.random(n // 10) < 0.5, 1.0, -1.0)
-    _same(O.trace(sc.desc, o, d, unit_dir=True), O.trace(sc.desc, o, d, unit_dir=True, cull=(boxes, info)))
+    _same(O.trace(sc.desc, o, d, unit_dir=True), O.trace(sc.desc, o, d, unit_dir=True, cull=cull))
 
     # origins beyond the culling radius, huge coordinates, non-unit and non-finite directions: the walk
     # must fall back to the literal one ray by ray (checker counts no culled node for them)
     far = (info[:3] + 3.0 * np.sqrt(info[3]) * d[:2000]).astype(np.float32)
     back = -d[:2000]
-    a, b = O.trace(sc.desc, far, back, unit_dir=True), O.trace(sc.desc, far, back, unit_dir=True, cull=(boxes, info))
+    a, b = O.trace(sc.desc, far, back, unit_dir=True), O.trace(sc.desc, far, back, unit_dir=True, cull=cull)
     _same(a, b)
     assert b["visits"][3] == 0 and (a["prim_id"] != 0xFFFFFFFF).any()
     bad_d = d[:3000].copy()
     bad_d[:1000, 0] = np.nan
     bad_d[1000:2000] *= 1.5
     bad_d[2000:3000, 1] = np.inf
-    a, b = O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True), O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True, cull=(boxes, info))
+    a, b = O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True), O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True, cull=cull)
     _same(a, b)
     assert b["visits"][3] == 0
 
@@ -81,7 +83,8 @@ def test_boxes_contain_their_primitives(built_scenes):
     """Structure of the cull data: a parent's box contains both children's, a leaf's box its primitives' vertices."""
     sc = built_scenes("teapot")
     d = sc.desc.contents
-    boxes, info = hip.cull_data(sc.desc)
+    qbox, info = hip.cull_data(sc.desc)
+    boxes = hip.cull_boxes_world(qbox, info)
     w0 = np.ctypeslib.as_array(d.node_w0, (d.n_nodes,))
     w1 = np.ctypeslib.as_array(d.node_w1, (d.n_nodes,))
     refs = np.ctypeslib.as_array(d.leaf_ref, (d.n_refs,))
@@ -106,4 +109,4 @@ def test_boxes_contain_their_primitives(built_scenes):
                 continue
             v = pos[:, r].reshape(3, 3)
             assert (v >= boxes[k, :3]).all() and (v <= boxes[k, 3:]).all()
-    assert info[4] >= 1.0 and info[3] > 0
+    assert info[4] >= 1.0 and info[3] > 0 and not (qbox[reach][:, 0] == 0xFFFFFFFF).any()
