@@ -33,9 +33,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 def alg_bytes(vi, vl, vp, vc, rays):
     """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d), for the walk the kernel actually does
     (subtree-box culling on): every node it fetches — inner, leaf, or fetched and culled — is the 8-B kd
-    node + its 24-B box = 32 B; (4 B leaf ref + 36 B vertex positions) per primitive test;
+    node + its 8-B quantised box = 16 B; (4 B leaf ref + 36 B vertex positions) per primitive test;
     64 B ray record read + 44 B hit record write per ray.  The N_* are the kernel's own counters."""
-    return 32 * (vi + vl + vc) + 40 * vp + (64 + 44) * rays
+    return 16 * (vi + vl + vc) + 40 * vp + (64 + 44) * rays
 
 
 def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):

@@ -77,6 +77,7 @@ struct rtx_scene {
     // frames so that a render loop does not pay hipMalloc/hipFree of gigabytes per frame
     void*    ws;
     uint64_t ws_bytes;
+    bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
     unsigned persist_blocks[4]; // resident grid of the persistent kernels: [count + 2 * culled] (0 = not queried yet)
 };
 
@@ -188,22 +189,25 @@ static int validate_desc(const rtx_scene_desc* d)
 // D of every vertex, E = max(|e1|, |e2|) and the determinant cut-off |a| >= alpha = 1e-4
 // (Triangle_HitAt, surfaces.c:135-177), standard forward error analysis of
 //     h = d x e2, a = e1.h, s = o - v0, u = (s.h)/a, q = s x e1, v = (d.q)/a, t = (e2.q)/a
-// gives |a - a*| <= 7 eps E^2, |u - u*|, |v - v*| <= (9 eps D E + |u*| 7 eps E^2)/alpha + eps and
-// |t - t*| <= (9 eps D E^2 + |t*| 7 eps E^2)/alpha + eps |t|   (x* = exact value).  So an accepted hit
+// (|delta s| <= eps |s|; |delta h|, per component <= 2 eps |d||e2|, so <= 3.5 eps E; a 3-term dot product adds
+// 3 eps |x||y|) gives |a - a*| <= 6.5 eps E^2, |u - u*|, |v - v*| <= (7.5 eps D E + |u*| 6.5 eps E^2)/alpha + eps and
+// |t - t*| <= (7.5 eps D E^2 + |t*| 6.5 eps E^2)/alpha + eps |t|   (x* = exact value).  So an accepted hit
 // (u, v >= 0, u + v <= 1, 1e-4 <= t <= tMax) has its exact plane point v0 + u* e1 + v* e2 inside the
 // triangle's bounds widened per axis by 4 beta ext_axis, at an exact ray parameter in
 // [-tau, tMax (1 + kappa') + tau]; a point within tau of the tested segment lies in the box widened by
 // tau.  Spheres (Sphere_HitAt, surfaces.c:55-87): the discriminant is off by at most
 // Delta = 24 eps (D^2 + r^2), so a reported root is within 2 sqrt(Delta) + 5 eps D of an exact point of
 // the sphere or of the ray's closest approach, which is then within sqrt(Delta) of the sphere.
-// All bounds are doubled; a triangle whose kappa = 7 eps E^2 / alpha reaches 1/4 (edges over ~7.7 units)
-// gets an unbounded box, i.e. is never culled.  The box test itself computes (b - o) * (1/d) in binary32:
+// All bounds carry a further factor 1.25; a triangle whose kappa = 6.5 eps E^2 / alpha reaches 1/4 (edges over
+// ~8 units) gets an unbounded box, i.e. is never culled.  The pads grow with D E / alpha: with big triangles
+// (beta ~ 1 and more) the boxes stop culling anything, and `useful` tells the launcher to walk literally.  The box test itself computes (b - o) * (1/d) in binary32:
 // its rounding equals a displacement of the box plane by <= 3 eps |b - o| <= 6 eps D, covered by 32 eps D.
 // ---------------------------------------------------------------------------------------------
 struct CullData {
     std::vector<uint4> nodes16; // {w0, w1, qmin, qmax}
     float              c[3], ro2, kt;
     float              lo[3], scale[3], iscale[3]; // quantisation grid: x = lo + q * scale
+    bool               useful;                     // median triangle pad below its own size
 };
 #define CULL_QBITS_X 11
 #define CULL_QBITS_Y 11
@@ -232,7 +236,9 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     double c[3], R = 0.0;
     for (int a = 0; a < 3; a++) c[a] = 0.5 * (lo[a] + hi[a]), R += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
     R               = sqrt(R) + 1e-6;
-    const double RO = 4.0 * R, D = 1.01 * (RO + R);
+    const double RO = 3.0 * R, D = 1.01 * (RO + R), SAFETY = 1.25;
+    std::vector<float> betas;
+    betas.reserve(T);
     for (int a = 0; a < 3; a++) out.c[a] = (float)c[a];
     out.ro2 = round_down(RO * RO * 0.999);
 
@@ -244,11 +250,12 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
         const float  e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
         const double E     = std::max(sqrt((double)e1[0] * e1[0] + (double)e1[1] * e1[1] + (double)e1[2] * e1[2]),
                                       sqrt((double)e2[0] * e2[0] + (double)e2[1] * e2[1] + (double)e2[2] * e2[2]));
-        const double kappa = 7.0 * EPS * E * E / ALPHA;
+        const double kappa = 6.5 * EPS * E * E / ALPHA;
         const bool   finite = std::isfinite(E) && kappa < 0.25;
-        const double beta  = finite ? 2.0 * ((9.0 * EPS * D * E / ALPHA + kappa + EPS) / (1.0 - kappa)) : 0.0;
-        const double tau   = finite ? 2.0 * (9.0 * EPS * D * E * E / ALPHA) / (1.0 - kappa) : 0.0;
-        if (finite) kappa_scene = std::max(kappa_scene, 2.0 * (kappa + 2.0 * EPS) / (1.0 - kappa));
+        const double beta  = finite ? SAFETY * ((7.5 * EPS * D * E / ALPHA + kappa + EPS) / (1.0 - kappa)) : 0.0;
+        const double tau   = finite ? SAFETY * (7.5 * EPS * D * E * E / ALPHA) / (1.0 - kappa) : 0.0;
+        if (finite) kappa_scene = std::max(kappa_scene, SAFETY * (kappa + 2.0 * EPS) / (1.0 - kappa));
+        betas.push_back(finite ? (float)beta : INFINITY);
         for (int a = 0; a < 3; a++) {
             // bounds over v0, v1, v2 and v0 + e1, v0 + e2 as the kernel's records hold them
             double x0 = p[a], x1 = p[3 + a], x2 = p[6 + a], y1 = (double)p[a] + e1[a], y2 = (double)p[a] + e2[a];
@@ -260,13 +267,18 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     }
     for (size_t i = 0; i < Sn; i++) {
         const double r = fabs((double)d->sph[3 * Sn + i]), Delta = 24.0 * EPS * (D * D + r * r);
-        const double pad = 2.0 * (3.0 * sqrt(Delta) + 5.0 * EPS * D) + 32.0 * EPS * D;
+        const double pad = SAFETY * (3.0 * sqrt(Delta) + 5.0 * EPS * D) + 32.0 * EPS * D;
         for (int a = 0; a < 3; a++) {
             plo[3 * (T + i) + a] = (double)d->sph[a * Sn + i] - r - pad;
             phi[3 * (T + i) + a] = (double)d->sph[a * Sn + i] + r + pad;
         }
     }
     out.kt = round_up(1.0 + kappa_scene + 64.0 * EPS);
+    out.useful = true;
+    if (!betas.empty()) {
+        std::nth_element(betas.begin(), betas.begin() + betas.size() / 2, betas.end());
+        out.useful = betas[betas.size() / 2] <= 1.0f;
+    }
 
     // subtree boxes, children before parents (explicit stack: the tree can be 60 levels deep but is not balanced)
     std::vector<double>   blo(3 * N, INFINITY), bhi(3 * N, -INFINITY);
@@ -388,6 +400,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_iscale[a] = cd.iscale[a];
         S.cull_ro2 = cd.ro2;
         S.cull_kt  = cd.kt;
+        sc->cull_useful = cd.useful;
     }
     {
         // Device-side triangle order = order of first appearance in the leaf reference stream (the
@@ -417,7 +430,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         }
         UP(upload(sc, refs.data(), refs.size(), &S.leaf_ref));
 
-        std::vector<float4>   hot(3 * T), cold(4 * T);
+        std::vector<float4>   hot((size_t)TRI_STRIDE * T), cold(4 * T);
         std::vector<uint32_t> obj(T);
         for (size_t j = 0; j < T; j++) {
             const size_t i = old_of_new[j];
@@ -427,9 +440,9 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
             // edge1 = v1 - v0, edge2 = v2 - v0 (surfaces.c:137-138), one binary32 subtraction each
             float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
             float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
-            hot[3 * j + 0]  = make_float4(p[0], p[1], p[2], e1x);
-            hot[3 * j + 1]  = make_float4(e1y, e1z, e2x, e2y);
-            hot[3 * j + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+            hot[TRI_STRIDE * j + 0]  = make_float4(p[0], p[1], p[2], e1x);
+            hot[TRI_STRIDE * j + 1]  = make_float4(e1y, e1z, e2x, e2y);
+            hot[TRI_STRIDE * j + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
             uint32_t mat    = d->tri_mat[i];
             float    matf;
             memcpy(&matf, &mat, 4);
@@ -649,7 +662,7 @@ DEV uint64_t wave_bcast_u64(uint64_t v)
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                        uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
-                                                       uint32_t chunk, uint64_t* counters)
+                                                       uint32_t chunk, uint64_t* counters, uint32_t /*tune*/)
 {
     const uint32_t lane    = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
                 if (r & RTX_REF_SPHERE) {
                     hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
                 } else {
-                    const float4* tp = S.tri + 3ull * r;
+                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
                     const float4  a = tp[0], b = tp[1], c = tp[2];
                     hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, RT_EPSILON, tMax, t, u, v);
                 }
@@ -864,8 +877,12 @@ DEV uint32_t xcc_id()
 template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
-                                                    uint32_t chunk, uint64_t* counters)
+                                                    uint32_t chunk, uint64_t* counters, uint32_t tune)
 {
+    // Block scheduling (wave-uniform): the INNER and LEAF blocks cost ~60 and ~90 vector instructions whatever
+    // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
+    // enough lanes wait for it (or nothing else can run); lanes in the other state simply keep their place.
+    const uint32_t leaf_min = tune & 0xFFu, inner_min = (tune >> 8) & 0xFFu, refill_min = (tune >> 16) & 0xFFu;
     const uint32_t lane    = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -897,7 +914,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
         const uint64_t idle  = __ballot(state == ST_IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (exhausted && nidle == 64u) break;
-        if (!exhausted && nidle >= REFILL_MIN) {
+        if (!exhausted && nidle >= refill_min) {
             if (next >= end) {
                 // The queue is cut into 8 contiguous parts, one per XCD (work[8 * part] = rays handed out of that
                 // part): the waves of an XCD drain their own part front to back, so the rays resident on an XCD
@@ -952,8 +969,11 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             continue;
         }
 
-        bool pop = false, fin = false;
-        if (state == ST_INNER) {
+        bool           pop = false, fin = false;
+        const uint32_t nI = (uint32_t)__popcll(__ballot(state == ST_INNER)), nL = 64u - nidle - nI;
+        const bool     doLeaf  = nL >= leaf_min || nI == 0u;
+        const bool     doInner = nI >= inner_min || !doLeaf;
+        if (doInner && state == ST_INNER) {
             uint2 nd;
             bool  culled = false;
             if (CULL) {
@@ -1017,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                 node = goRight ? right : idx;
                 tMax = both ? tMaxN : tMax;
             }
-        } else if (state == ST_LEAF) {
+        } else if (doLeaf && state == ST_LEAF) {
             const uint32_t r = curRef;
             if (leafPos + 1 < leafEnd) curRef = S.leaf_ref[leafPos + 1]; // next reference in flight
             if (COUNT) vis.prim++;
@@ -1026,9 +1046,16 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             if (r & RTX_REF_SPHERE) {
                 hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
             } else {
-                const float4* tp = S.tri + 3ull * r;
-                const float4  a = tp[0], b = tp[1];
-                const float   cx = *(const float*)(tp + 2); // 36 of the record's 48 bytes
+                const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
+                float4        a  = tp[0];
+#if TRI_WAIT
+                // One L2 request per triangle instead of three: a vector-L1 miss is not merged with a miss already
+                // pending on the same line (probe: tools/dbg/line.hip), and this kernel's bounce passes are bound by
+                // the number of L2 requests.  So take the first 16 bytes, wait, and read the rest from L1.
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)::"memory");
+#endif
+                const float4 b  = tp[1];
+                const float  cx = *(const float*)(tp + 2); // 36 bytes of the record are used
                 hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cx), o, d, RT_EPSILON, tMax, t, u, v);
             }
             if (hit && t < bestT) { // strict: first in list wins ties (kdtree.c:485)
@@ -1327,7 +1354,8 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
 {
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
-    const int variant = literal ? std::min(trace_variant(), 2) : trace_variant();
+    // default: the culled walk where its boxes help, else the literal one; RTX_TRACE_VARIANT overrides
+    const int variant = literal ? std::min(trace_variant(), 2) : (trace_variant() == 3 && !getenv("RTX_TRACE_VARIANT") && !sc->cull_useful) ? 2 : trace_variant();
     if (variant == 0) {
         unsigned nb = blocks_for(n, 64);
         if (count) {
@@ -1340,7 +1368,15 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     }
     // persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
     // that would not fit simply start later and find the queue empty — nothing waits on another block)
-    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*);
+    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t);
+    static uint32_t tune = 0;
+    if (tune == 0) { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes)
+        unsigned    a = 16, b = 8, c = REFILL_MIN;
+        const char* e = getenv("RTX_TRACE_TUNE");
+        if (e) sscanf(e, "%u,%u,%u", &a, &b, &c);
+        a = std::min(std::max(a, 1u), 64u), b = std::min(std::max(b, 1u), 64u), c = std::min(std::max(c, 1u), 64u);
+        tune = a | b << 8 | c << 16;
+    }
     PersistKernel kern    = variant == 1   ? (count ? k_trace_persist<true> : k_trace_persist<false>)
                             : variant == 2 ? (count ? k_trace_flat<true, false> : k_trace_flat<false, false>)
                                            : (count ? k_trace_flat<true, true> : k_trace_flat<false, true>);
@@ -1351,6 +1387,7 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
+        if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // experiments
         sc->persist_blocks[slot] = (unsigned)(per_cu * cus);
     }
     unsigned long long* work = (unsigned long long*)&sc->d_counters[16]; // 8 part counters, 64 B apart
@@ -1361,7 +1398,7 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     uint64_t chunk = n / (waves * 8);
     chunk          = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + 255) / 256);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }

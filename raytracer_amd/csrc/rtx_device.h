@@ -15,6 +15,12 @@
 #define PI32 3.141592653589793238462643383279502884197169399375105820f // src/math/math.h:7
 #define RTX_INF (__builtin_inff())
 #define RTX_STACK 64 // >= desc.max_depth (checked at rtx_scene_create)
+#ifndef TRI_STRIDE
+#define TRI_STRIDE 4 // float4 per hot triangle record: 64 B, one cache line each (36 B used)
+#endif
+#ifndef TRI_WAIT
+#define TRI_WAIT 1
+#endif
 
 #define DEV __device__ __forceinline__
 
@@ -37,7 +43,7 @@ struct SceneDev {
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
     float           cull_lo[3], cull_scale[3], cull_iscale[3];
     const uint32_t* leaf_ref; // pool bit | pool index
-    // hot triangle pool, 48 B per triangle:
+    // hot triangle pool, 16 * TRI_STRIDE bytes per triangle:
     //   [0] = v0.x v0.y v0.z e1.x   [1] = e1.y e1.z e2.x e2.y   [2] = e2.z 0 0 0
     // e1 = v1-v0, e2 = v2-v0: the two subtractions Triangle_HitAt redoes on every call
     // (src/rt/surfaces.c:137-138), hoisted to upload time; the rounded results are identical.
@@ -343,7 +349,7 @@ DEV void closest_hit(const SceneDev& S, const RayD& ray, uint32_t& ref, float& t
                 if (r & RTX_REF_SPHERE) {
                     hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], ray.o, ray.d, RT_EPSILON, tMax, t);
                 } else {
-                    const float4* tp = S.tri + 3ull * r;
+                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
                     const float4  a = tp[0], b = tp[1], c = tp[2];
                     hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), ray.o, ray.d, RT_EPSILON,
                                          tMax, t, u, v);
