@@ -182,7 +182,7 @@ def main():
                 a = torch.zeros(h, w, 3, dtype=torch.float32, device=dev)
                 s = ds.render_device(cam, hip.make_params(w, h, spp, depth, seed=(1, 2)), a.data_ptr(), stream)
                 return s["rays_total"]
-            out["cpu_baseline"] = cpu_baseline(args.scene, 480, 270, args.spp, args.depth, gpu_rays)
+            out["cpu_baseline"] = cpu_baseline(args.scene, 1280, 720, args.spp, args.depth, gpu_rays)
         if args.save_bmp:
             from raytracer_amd import host
             import ctypes as C

@@ -1193,24 +1193,40 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
     }
 }
 
-// RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel
+// RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel, in sample
+// order.  A pixel's samples are contiguous in the result slab, so a thread that walked its own pixel would
+// read with a 4*spp-byte stride between lanes; instead the block stages 256 pixels x 16 samples at a time
+// through LDS (64-byte runs per pixel on the global side, stride-17 rows on the LDS side: conflict-free).
+#define RESOLVE_CH 16
 __global__ __launch_bounds__(256) void k_resolve_slab(const float* __restrict__ result, uint64_t rcap, FrameGeom g,
                                                        uint64_t first_pixel, uint64_t n_pixels, float* __restrict__ accum)
 {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_tile[256 * (RESOLVE_CH + 1)];
+    const uint64_t p0 = (uint64_t)blockIdx.x * 256;
+    const uint64_t p  = p0 + threadIdx.x;
+    const uint32_t ns = g.n_samples;
+    float          cum[3] = {0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < 3; c++) {
+        for (uint32_t k = 0; k < ns; k += RESOLVE_CH) {
+            const uint32_t len = min((uint32_t)RESOLVE_CH, ns - k);
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < 256u * RESOLVE_CH; e += 256u) {
+                const uint32_t j = e / RESOLVE_CH, sIdx = e % RESOLVE_CH;
+                if (sIdx < len && p0 + j < n_pixels) s_tile[j * (RESOLVE_CH + 1) + sIdx] = result[c * rcap + (p0 + j) * ns + k + sIdx];
+            }
+            __syncthreads();
+            if (p < n_pixels)
+                for (uint32_t sIdx = 0; sIdx < len; sIdx++) cum[c] = cum[c] + s_tile[threadIdx.x * (RESOLVE_CH + 1) + sIdx];
+        }
+    }
     if (p >= n_pixels) return;
     uint64_t pl = first_pixel + slab_pixel(g, p);
     uint32_t xx = (uint32_t)(pl % g.width);
     uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
-    f3       cum = mk3(0, 0, 0);
-    uint64_t b   = p * g.n_samples;
-    for (uint32_t s = 0; s < g.n_samples; s++) {
-        cum = vadd(cum, mk3(result[0 * rcap + b + s], result[1 * rcap + b + s], result[2 * rcap + b + s]));
-    }
-    uint64_t o = ((uint64_t)yy * g.width + xx) * 3;
-    accum[o + 0] += cum.x;
-    accum[o + 1] += cum.y;
-    accum[o + 2] += cum.z;
+    uint64_t o  = ((uint64_t)yy * g.width + xx) * 3;
+    accum[o + 0] += cum[0];
+    accum[o + 1] += cum[1];
+    accum[o + 2] += cum[2];
 }
 
 DEV uint8_t LinearTosRGB(float channel) // src/gfx/color.c:18-29
