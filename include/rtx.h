@@ -176,6 +176,7 @@ typedef struct rtx_stats {
     uint32_t passes; /* slabs */
     double   ms_trace_at_depth[RTX_MAX_DEPTH]; /* closest-hit kernel time per ray depth */
     uint64_t visits_culled; /* nodes fetched and skipped by the box test (COUNT_VISITS, culled walk) */
+    double   ms_sort;       /* ray binning between bounce passes */
 } rtx_stats;
 
 /* ---- library ---- */

@@ -25,6 +25,12 @@
 #include "rtx.h"
 #include "rtx_device.h"
 
+// ray binning between bounce passes (see k_bin_count): cells per axis = 2^BIN_CELL_BITS, times 8 direction octants
+#ifndef BIN_CELL_BITS
+#define BIN_CELL_BITS 5
+#endif
+#define BIN_BITS (3 * BIN_CELL_BITS + 3)
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------
@@ -400,6 +406,8 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_iscale[a] = cd.iscale[a];
         S.cull_ro2 = cd.ro2;
         S.cull_kt  = cd.kt;
+        const int lv[3] = {(1 << CULL_QBITS_X) - 1, (1 << CULL_QBITS_Y) - 1, (1 << CULL_QBITS_Z) - 1};
+        for (int a = 0; a < 3; a++) S.bin_inv[a] = (float)(1 << BIN_CELL_BITS) / (cd.scale[a] * (float)lv[a]); // cells over the box grid
         sc->cull_useful = cd.useful;
     }
     {
@@ -1193,6 +1201,109 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ray binning between bounce passes.  The closest-hit passes of depth >= 2 are bound by the rate of L2
+// misses (rocprof: ~51 G misses/s against a measured ~58 G/s ceiling for 64-byte gathers that miss L2,
+// tools/dbg/gather.hip): the rays of a wave start all over the model.  A counting sort of the queue by
+// (origin cell on a 32^3 grid in Morton order, direction octant) puts rays that will walk the same part of
+// the tree next to each other, i.e. on the same XCD at the same time (see part_begin).  Order inside a bin
+// is arbitrary; results do not depend on queue order (per-path RNG state and result slot).
+// ---------------------------------------------------------------------------------------------
+
+DEV uint32_t spread3(uint32_t v) // up to 6 bits -> every third bit
+{
+    return (v & 1u) | (v & 2u) << 2 | (v & 4u) << 4 | (v & 8u) << 6 | (v & 16u) << 8 | (v & 32u) << 10;
+}
+DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d)
+{
+    uint32_t c[3];
+    const float oo[3] = {o.x, o.y, o.z};
+    for (int a = 0; a < 3; a++) {
+        float f = (oo[a] - S.cull_lo[a]) * S.bin_inv[a]; // NaN / out of range: clamped below
+        f       = fminf(fmaxf(f, 0.0f), (float)((1 << BIN_CELL_BITS) - 1));
+        c[a]    = (uint32_t)f;
+    }
+    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    return (spread3(c[0]) | spread3(c[1]) << 1 | spread3(c[2]) << 2) << 3 | oct;
+}
+
+// One atomic per wave and distinct key: neighbours in the queue mostly share a bin, and same-address atomics
+// from every lane would serialise (the first version of this pass cost more than the traversal it helped).
+// Returns the lane's rank among the wave's lanes with the same key and, in `base`, what the leader's atomic
+// returned (valid in every lane of the group).
+DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint32_t& base)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t       rank = 0, my_leader = lane, gsize = 0;
+    // group the lanes by key with ballots only; the atomics of all group leaders then go out in ONE instruction
+    // (a loop with one atomic round trip per distinct key made the pass latency-bound)
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const uint32_t           leader = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t           k      = __shfl(key, (int)leader);
+        const unsigned long long grp    = __ballot(active && key == k) & todo;
+        if (active && key == k) {
+            my_leader = leader;
+            rank      = (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+            gsize     = (uint32_t)__popcll(grp);
+        }
+        todo &= ~grp;
+    }
+    uint32_t b = 0;
+    if (active && lane == my_leader) b = atomicAdd(&counters[key], gsize);
+    base = __shfl(b, (int)my_leader);
+    return rank;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(SceneDev S, Queue q, uint64_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ keys)
+{
+    uint64_t   i      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    uint32_t   key    = 0;
+    if (active) {
+        key     = ray_bin(S, mk3(q.f(Q_OX, i), q.f(Q_OY, i), q.f(Q_OZ, i)), mk3(q.f(Q_DX, i), q.f(Q_DY, i), q.f(Q_DZ, i)));
+        keys[i] = key;
+    }
+    uint32_t base;
+    (void)wave_group_add(counts, key, active, base);
+}
+
+// exclusive prefix sum of the 2^BIN_BITS counters, in place (one block)
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t per = (1u << BIN_BITS) / 1024u, b0 = threadIdx.x * per;
+    uint32_t       t = 0;
+    for (uint32_t k = 0; k < per; k++) t += counts[b0 + k];
+    s_sum[threadIdx.x] = t;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - t;
+    for (uint32_t k = 0; k < per; k++) {
+        uint32_t c     = counts[b0 + k];
+        counts[b0 + k] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ keys, Queue qout)
+{
+    uint64_t       i      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool     active = i < n;
+    const uint32_t key    = active ? keys[i] : 0u;
+    uint32_t       base;
+    const uint32_t rank = wave_group_add(offsets, key, active, base);
+    if (!active) return;
+    const uint64_t pos = (uint64_t)base + rank;
+#pragma unroll
+    for (int c = 0; c < Q_COMPONENTS; c++) qout.u(c, pos) = qin.u(c, i);
+}
+
 // RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel, in sample
 // order.  A pixel's samples are contiguous in the result slab, so a thread that walked its own pixel would
 // read with a 4*spp-byte stride between lanes; instead the block stages 256 pixels x 16 samples at a time
@@ -1572,10 +1683,23 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
 
     const uint64_t qbytes = cap * Q_COMPONENTS * 4;
     char*          ws     = nullptr;
-    if ((rc = workspace(sc, 2 * qbytes + cap * 16 + cap * 12, &ws)) != RTX_OK) return rc;
-    Queue  q[2]   = {{(float*)ws, cap}, {(float*)(ws + qbytes), cap}};
-    Hits   hits   = {(uint32_t*)(ws + 2 * qbytes), cap};
-    float* result = (float*)(ws + 2 * qbytes + cap * 16);
+    const uint64_t bin_bytes = (4ull << BIN_BITS);
+    if ((rc = workspace(sc, 2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes, &ws)) != RTX_OK) return rc;
+    Queue     q[2]     = {{(float*)ws, cap}, {(float*)(ws + qbytes), cap}};
+    Hits      hits     = {(uint32_t*)(ws + 2 * qbytes), cap};
+    float*    result   = (float*)(ws + 2 * qbytes + cap * 16);
+    uint32_t* bin_keys = (uint32_t*)(ws + 2 * qbytes + cap * 16 + cap * 12);
+    uint32_t* bin_cnt  = (uint32_t*)(ws + 2 * qbytes + cap * 16 + cap * 12 + cap * 4);
+    static int sort_depth = -1; // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never)
+    if (sort_depth < 0) {
+        const char* e = getenv("RTX_SORT_DEPTH");
+        sort_depth    = e ? atoi(e) : 2;
+    }
+    static int sort_every = 0; // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
+    if (sort_every == 0) {
+        const char* e = getenv("RTX_SORT_EVERY");
+        sort_every    = e ? std::max(1, atoi(e)) : 1;
+    }
 
     unsigned long long* d_cnt    = (unsigned long long*)&sc->d_counters[6];
     unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
@@ -1634,6 +1758,16 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
             }
             n   = alive;
             cur ^= 1;
+            if (sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && n >= 65536) {
+                HIPCHECK(hipMemsetAsync(bin_cnt, 0, bin_bytes, st));
+                rc = timed(4, [&] {
+                    hipLaunchKernelGGL(k_bin_count, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc->dev, q[cur], n, bin_cnt, bin_keys);
+                    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, bin_cnt);
+                    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, st, q[cur], n, bin_cnt, bin_keys, q[cur ^ 1]);
+                });
+                if (rc != RTX_OK) return rc;
+                cur ^= 1;
+            }
         }
         rc = timed(3, [&] {
             hipLaunchKernelGGL(k_resolve_slab, dim3(blocks_for(npx, 256)), dim3(256), 0, st, result, cap, gs, px0, npx, d_accum);
@@ -1647,7 +1781,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     local.ms_total = ms;
     for (const Span& s : spans) {
         HIPCHECK(hipEventElapsedTime(&ms, sc->ev[s.a], sc->ev[s.b]));
-        (s.kind == 0 ? local.ms_raygen : s.kind == 1 ? local.ms_trace : s.kind == 2 ? local.ms_shade : local.ms_resolve) += ms;
+        (s.kind == 0 ? local.ms_raygen : s.kind == 1 ? local.ms_trace : s.kind == 2 ? local.ms_shade : s.kind == 3 ? local.ms_resolve : local.ms_sort) += ms;
         if (s.kind == 1) local.ms_trace_at_depth[s.depth] += ms;
     }
     uint64_t c[5];

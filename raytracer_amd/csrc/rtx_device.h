@@ -42,6 +42,7 @@ struct SceneDev {
     float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
     float           cull_lo[3], cull_scale[3], cull_iscale[3];
+    float           bin_inv[3]; // ray binning: 32 cells per axis over the box grid, cell = (o - cull_lo) * bin_inv
     const uint32_t* leaf_ref; // pool bit | pool index
     // hot triangle pool, 16 * TRI_STRIDE bytes per triangle:
     //   [0] = v0.x v0.y v0.z e1.x   [1] = e1.y e1.z e2.x e2.y   [2] = e2.z 0 0 0

@@ -20,7 +20,7 @@ for f in range(frames):
 out = {"scene": scene, "w": w, "h": h, "spp": spp, "depth": depth, "rays": st["rays_at_depth"],
        "ms": [round(x, 3) for x in st["ms_trace_at_depth"]],
        "mrays_s": [round(r / m / 1e3, 1) for r, m in zip(st["rays_at_depth"], st["ms_trace_at_depth"])],
-       "ms_trace": st["ms_trace"], "ms_shade": st["ms_shade"], "ms_total": st["ms_total"],
+       "ms_trace": st["ms_trace"], "ms_shade": st["ms_shade"], "ms_sort": st["ms_sort"], "ms_total": st["ms_total"],
        "total_mrays_s": st["rays_total"] / st["ms_total"] / 1e3}
 if flags:
     out["visits_per_ray"] = [st[k] / st["rays_total"] for k in ("visits_inner", "visits_leaf", "visits_prim")]
