@@ -137,7 +137,7 @@ def main():
                                          st_count["rays_total"])),
                          float(st_count["rays_total"]), float(st_count["visits_inner"]), float(st_count["visits_leaf"]), float(st_count["visits_prim"]),
                          sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats),
-                         float(st_count["visits_culled"])],
+                         float(st_count["visits_culled"]), sum(s["ms_sort"] for s in stats)],
                         dtype=torch.float64, device=dev)
     tmax = vals[:1].clone()
     if world > 1:
@@ -172,7 +172,8 @@ def main():
                        "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame,
                                           "fetched_and_culled": v[12] / rays_frame},
                        "kernel_ms_per_frame": {"trace": ms_trace / args.steps / world, "shade": v[9] / args.steps / world,
-                                               "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world}},
+                                               "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world,
+                                               "ray_binning": v[13] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_trace_flat<false,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
                          "alg_bytes_per_ray": bytes_frame / rays_frame},
