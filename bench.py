@@ -90,11 +90,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to benchmark)")
+    # RTX_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo — to rehearse the N > 1 path on a one-GPU box
+    rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     sc = scenes.build(args.scene)
     ds = hip.DeviceScene(sc.desc, local_rank)

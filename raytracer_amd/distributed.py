@@ -59,5 +59,8 @@ def reduce_to_rank0(accum, group=None):
     """Sum-reduce the f32 accumulation tensor to rank 0 (no-op for a single process)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on one GPU: gloo has no CUDA reduce
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
     return accum
