@@ -509,12 +509,13 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
 // ---------------------------------------------------------------------------------------------
 enum { Q_OX, Q_OY, Q_OZ, Q_DX, Q_DY, Q_DZ, Q_TR, Q_TG, Q_TB, Q_S0, Q_S1, Q_S2, Q_S3, Q_PID, Q_COMPONENTS };
 
-struct Queue {
+struct Queue { // component c of path i at base[c * cs + i * es]
     float*   base;
-    uint64_t cap;
-    DEV float&    f(int c, uint64_t i) const { return base[(uint64_t)c * cap + i]; }
-    DEV uint32_t& u(int c, uint64_t i) const { return ((uint32_t*)base)[(uint64_t)c * cap + i]; }
+    uint64_t cs, es; // SoA: cs = capacity, es = 1;  AoS (16-dword = 64-byte records, after binning): cs = 1, es = 16
+    DEV float&    f(int c, uint64_t i) const { return base[(uint64_t)c * cs + i * es]; }
+    DEV uint32_t& u(int c, uint64_t i) const { return ((uint32_t*)base)[(uint64_t)c * cs + i * es]; }
 };
+#define Q_RECORD 16 // dwords per path in an AoS queue (14 used)
 
 struct Hits { // SoA: ref, t, u, v
     uint32_t* base;
@@ -627,8 +628,9 @@ __global__ __launch_bounds__(64) void k_trace(SceneDev S, const float* __restric
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     Visits   vis = {0, 0, 0};
     if (i < n) {
-        f3       o = mk3(rays[0 * stride + i], rays[1 * stride + i], rays[2 * stride + i]);
-        f3       d = mk3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        const uint64_t cs = stride ? stride : 1, rb = i * (stride ? 1 : Q_RECORD); // stride 0: AoS records
+        f3       o = mk3(rays[0 * cs + rb], rays[1 * cs + rb], rays[2 * cs + rb]);
+        f3       d = mk3(rays[3 * cs + rb], rays[4 * cs + rb], rays[5 * cs + rb]);
         RayD     r = ray_from_unit(o, d);
         uint32_t ref;
         float    t, u, v;
@@ -713,8 +715,9 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
                 const uint32_t rank  = (uint32_t)__popcll(idle & lt_mask);
                 if (!active && rank < take) {
                     ridx = next + rank;
-                    o    = mk3(rays[0 * stride + ridx], rays[1 * stride + ridx], rays[2 * stride + ridx]);
-                    d    = mk3(rays[3 * stride + ridx], rays[4 * stride + ridx], rays[5 * stride + ridx]);
+                    const uint64_t cs = stride ? stride : 1, rb = (uint64_t)ridx * (stride ? 1 : Q_RECORD); // stride 0: AoS records
+                    o    = mk3(rays[0 * cs + rb], rays[1 * cs + rb], rays[2 * cs + rb]);
+                    d    = mk3(rays[3 * cs + rb], rays[4 * cs + rb], rays[5 * cs + rb]);
                     inv  = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13)
                     odd  = vdivc(o, d);
                     // keep the six quotients in registers: without this the optimiser sinks the
@@ -949,8 +952,9 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                 const uint32_t rank  = (uint32_t)__popcll(idle & lt_mask);
                 if (state == ST_IDLE && rank < take) {
                     ridx = (uint32_t)(next + rank);
-                    o    = mk3(rays[0 * stride + ridx], rays[1 * stride + ridx], rays[2 * stride + ridx]);
-                    d    = mk3(rays[3 * stride + ridx], rays[4 * stride + ridx], rays[5 * stride + ridx]);
+                    const uint64_t cs = stride ? stride : 1, rb = (uint64_t)ridx * (stride ? 1 : Q_RECORD); // stride 0: AoS records
+                    o    = mk3(rays[0 * cs + rb], rays[1 * cs + rb], rays[2 * cs + rb]);
+                    d    = mk3(rays[3 * cs + rb], rays[4 * cs + rb], rays[5 * cs + rb]);
                     inv  = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13)
                     odd  = vdivc(o, d);
                     if (CULL) {
@@ -1125,9 +1129,12 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
 // per-wave atomic the 2.6 M same-address atomics of a 1080p/64 spp pass, ~12 ns each, WERE the kernel's
 // run time — rocprof: 6 % VALU busy, 84 % of wave time waiting.)
 #define SHADE_BLOCK 1024
+DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d);
+DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint32_t& base);
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
                                                        unsigned long long* out_count, unsigned long long* shaded_count,
-                                                       float* __restrict__ result, uint64_t rcap, int last)
+                                                       float* __restrict__ result, uint64_t rcap, int last,
+                                                       uint32_t* __restrict__ bin_cnt, uint32_t* __restrict__ bin_keys)
 {
     __shared__ uint32_t s_wave_cnt[SHADE_BLOCK / 64], s_wave_shaded[SHADE_BLOCK / 64];
     __shared__ uint64_t s_base;
@@ -1199,6 +1206,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
         qout.u(Q_S0, pos) = rng.s0, qout.u(Q_S1, pos) = rng.s1, qout.u(Q_S2, pos) = rng.s2, qout.u(Q_S3, pos) = rng.s3;
         qout.u(Q_PID, pos) = pid;
     }
+    if (bin_cnt) { // first half of the binning pass (k_bin_scan / k_bin_scatter follow): key and histogram
+        const uint32_t key = alive ? ray_bin(S, o2, d2) : 0u;
+        if (alive) {
+            uint64_t pos = s_base + rank;
+            for (uint32_t w = 0; w < wave; w++) pos += s_wave_cnt[w];
+            bin_keys[pos] = key;
+        }
+        uint32_t base;
+        (void)wave_group_add(bin_cnt, key, alive, base); // one atomic per wave and key
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1255,19 +1272,6 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
     return rank;
 }
 
-__global__ __launch_bounds__(256) void k_bin_count(SceneDev S, Queue q, uint64_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ keys)
-{
-    uint64_t   i      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
-    uint32_t   key    = 0;
-    if (active) {
-        key     = ray_bin(S, mk3(q.f(Q_OX, i), q.f(Q_OY, i), q.f(Q_OZ, i)), mk3(q.f(Q_DX, i), q.f(Q_DY, i), q.f(Q_DZ, i)));
-        keys[i] = key;
-    }
-    uint32_t base;
-    (void)wave_group_add(counts, key, active, base);
-}
-
 // exclusive prefix sum of the 2^BIN_BITS counters, in place (one block)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts)
 {
@@ -1300,8 +1304,14 @@ __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint
     const uint32_t rank = wave_group_add(offsets, key, active, base);
     if (!active) return;
     const uint64_t pos = (uint64_t)base + rank;
+    // the destination is an AoS queue: one 64-byte record = one line per path, instead of 14 dwords on 14 lines
+    uint32_t w[Q_RECORD];
 #pragma unroll
-    for (int c = 0; c < Q_COMPONENTS; c++) qout.u(c, pos) = qin.u(c, i);
+    for (int c = 0; c < Q_COMPONENTS; c++) w[c] = qin.u(c, i);
+    w[14] = w[15] = 0u;
+    uint4* dst = (uint4*)((uint32_t*)qout.base + pos * Q_RECORD);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
 // RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel, in sample
@@ -1681,11 +1691,13 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     const uint64_t cap   = px_per_slab * g.n_samples;
     if (cap > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "spp too large for one slab");
 
-    const uint64_t qbytes = cap * Q_COMPONENTS * 4;
+    const uint64_t qbytes = cap * Q_RECORD * 4;
     char*          ws     = nullptr;
     const uint64_t bin_bytes = (4ull << BIN_BITS);
     if ((rc = workspace(sc, 2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes, &ws)) != RTX_OK) return rc;
-    Queue     q[2]     = {{(float*)ws, cap}, {(float*)(ws + qbytes), cap}};
+    float*    qb[2]    = {(float*)ws, (float*)(ws + qbytes)};
+    auto      soa      = [&](int b) { return Queue{qb[b], cap, 1}; };
+    auto      aos      = [&](int b) { return Queue{qb[b], 1, Q_RECORD}; };
     Hits      hits     = {(uint32_t*)(ws + 2 * qbytes), cap};
     float*    result   = (float*)(ws + 2 * qbytes + cap * 16);
     uint32_t* bin_keys = (uint32_t*)(ws + 2 * qbytes + cap * 16 + cap * 12);
@@ -1734,21 +1746,24 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         HIPCHECK(hipMemsetAsync(result, 0, cap * 12, st));
         FrameGeom gs = g; // tile-major path order when the slab is made of whole rows
         if (px0 % g.width == 0 && npx % g.width == 0 && npx / g.width >= 2 * PATH_TILE) gs.tile = PATH_TILE, gs.slab_rows = (uint32_t)(npx / g.width);
-        rc = timed(0, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, st, *cam, gs, px0, n, q[0]); });
+        rc = timed(0, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, st, *cam, gs, px0, n, soa(0)); });
         if (rc != RTX_OK) return rc;
-        int cur = 0;
+        int   cur = 0;       // buffer that holds the queue of this depth
+        Queue qin = soa(0);  // its layout: SoA out of raygen / shade, AoS out of the binning pass
         for (uint32_t depth = 0; depth < p->max_depth && n > 0; depth++) {
             local.rays_at_depth[depth] += n;
             local.rays_total += n;
             cur_depth = depth;
-            rc = timed(1, [&] { (void)launch_trace(sc, q[cur].base, cap, n, hits.base, cap, st, count, sc->d_counters, literal); });
+            rc = timed(1, [&] { (void)launch_trace(sc, qin.base, qin.es == 1 ? cap : 0, n, hits.base, cap, st, count, sc->d_counters, literal); });
             if (rc != RTX_OK) return rc;
             local.trace_launches++;
             HIPCHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-            const int last = depth + 1 == p->max_depth;
+            const int  last = depth + 1 == p->max_depth;
+            const bool bin  = !last && sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && n >= 65536;
+            if (bin) HIPCHECK(hipMemsetAsync(bin_cnt, 0, bin_bytes, st));
             rc = timed(2, [&] {
-                hipLaunchKernelGGL(k_shade, dim3(blocks_for(n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc->dev, q[cur], hits, n, q[cur ^ 1], d_cnt, d_shaded,
-                                   result, cap, last);
+                hipLaunchKernelGGL(k_shade, dim3(blocks_for(n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc->dev, qin, hits, n, soa(cur ^ 1), d_cnt, d_shaded,
+                                   result, cap, last, bin ? bin_cnt : nullptr, bin_keys);
             });
             if (rc != RTX_OK) return rc;
             unsigned long long alive = 0;
@@ -1758,15 +1773,15 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
             }
             n   = alive;
             cur ^= 1;
-            if (sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && n >= 65536) {
-                HIPCHECK(hipMemsetAsync(bin_cnt, 0, bin_bytes, st));
+            qin = soa(cur);
+            if (bin && n > 0) {
                 rc = timed(4, [&] {
-                    hipLaunchKernelGGL(k_bin_count, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc->dev, q[cur], n, bin_cnt, bin_keys);
                     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, bin_cnt);
-                    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, st, q[cur], n, bin_cnt, bin_keys, q[cur ^ 1]);
+                    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, st, qin, n, bin_cnt, bin_keys, aos(cur ^ 1));
                 });
                 if (rc != RTX_OK) return rc;
                 cur ^= 1;
+                qin = aos(cur);
             }
         }
         rc = timed(3, [&] {
