@@ -918,6 +918,8 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     uint32_t leafPos = 0, leafEnd = 0, curRef = 0;
     float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
     uint32_t best = HIT_MISS;
+    float    pBest = RTX_INF;  // closest hit in the unbounded (plane) list, found when the ray is loaded
+    uint32_t pRef  = HIT_MISS;
     bool     cullOK = false; // this lane's ray meets the preconditions of the box bounds
     Visits   vis  = {0, 0, 0, 0};
 
@@ -970,6 +972,18 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                         cullOK         = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f; // false for any NaN / inf component
                     }
                     asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                    // Scene_ClosestHitInArray (scene.c:73-98) does not depend on the tree walk: done here, where at
+                    // least refill_min lanes share the instructions, instead of in FIN where one or two lanes do
+                    pBest = RTX_INF;
+                    pRef  = HIT_MISS;
+                    for (uint32_t i = 0; i < S.n_planes; i++) {
+                        const float* pl = S.plane + 8ull * i;
+                        float        tp2;
+                        if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                            pBest = tp2;
+                            pRef  = HIT_PLANE | i;
+                        }
+                    }
                     node  = S.root;
                     tMax  = RTX_INF;
                     sp    = 0;
@@ -1103,16 +1117,6 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             uint32_t ref = best;
             float    tH = bestT, uH = bu, vH = bv;
             if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
-            float    pBest = RTX_INF;
-            uint32_t pRef  = HIT_MISS;
-            for (uint32_t i = 0; i < S.n_planes; i++) { // Scene_ClosestHitInArray (scene.c:73-98)
-                const float* pl = S.plane + 8ull * i;
-                float        tp2;
-                if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
-                    pBest = tp2;
-                    pRef  = HIT_PLANE | i;
-                }
-            }
             if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f; // scene.c:122-142
             hits[0 * hstride + ridx] = ref;
             hits[1 * hstride + ridx] = __float_as_uint(tH);
