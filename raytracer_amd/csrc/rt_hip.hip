@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
 // ---------------------------------------------------------------------------------------------
 enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2 };
 #ifndef LDS_SLOTS
-#define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave
+#define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave (16 slots: fewer blocks per CU, 14 % slower)
 #endif
 
 // start of part p (0..8) of an n-ray queue: eighths, rounded up to whole 64-ray groups
