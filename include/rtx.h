@@ -177,6 +177,9 @@ typedef struct rtx_stats {
     double   ms_trace_at_depth[RTX_MAX_DEPTH]; /* closest-hit kernel time per ray depth */
     uint64_t visits_culled; /* nodes fetched and skipped by the box test (COUNT_VISITS, culled walk) */
     double   ms_sort;       /* ray binning between bounce passes */
+    /* COUNT_VISITS, rtx_render*: closest-hit wave statistics summed over waves — loop iterations, INNER block
+     * runs and the lanes they served, LEAF runs and lanes, POP runs and lanes, FIN runs */
+    uint64_t wave_stats[8];
 } rtx_stats;
 
 /* ---- library ---- */

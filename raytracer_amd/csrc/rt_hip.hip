@@ -915,13 +915,14 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     int      sp   = 0;   // stack height
     int      base = 0;   // entries [base, sp) are in LDS, [0, base) in scratch
     uint2    stk[RTX_STACK];
-    uint32_t leafPos = 0, leafEnd = 0, curRef = 0;
+    uint32_t leafPos = 0, leafEnd = 0, curRef = 0, curRef2 = 0; // curRef(2): references leafPos, leafPos + 1, prefetched
     float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
     uint32_t best = HIT_MISS;
     float    pBest = RTX_INF;  // closest hit in the unbounded (plane) list, found when the ray is loaded
     uint32_t pRef  = HIT_MISS;
     bool     cullOK = false; // this lane's ray meets the preconditions of the box bounds
     Visits   vis  = {0, 0, 0, 0};
+    uint32_t ws[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // COUNT: iterations, INNER runs / lanes, LEAF runs / lanes, POP runs / lanes, FIN runs
 
     for (;;) {
         const uint64_t idle  = __ballot(state == ST_IDLE);
@@ -999,6 +1000,11 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
         const uint32_t nI = (uint32_t)__popcll(__ballot(state == ST_INNER)), nL = 64u - nidle - nI;
         const bool     doLeaf  = nL >= leaf_min || nI == 0u;
         const bool     doInner = nI >= inner_min || !doLeaf;
+        if (COUNT) { // wave statistics (wave-uniform): block executions and the lanes they served
+            ws[0]++;
+            if (doInner && nI) ws[1]++, ws[2] += nI;
+            if (doLeaf && nL) ws[3]++, ws[4] += nL;
+        }
         if (doInner && state == ST_INNER) {
             uint2 nd;
             bool  culled = false;
@@ -1032,6 +1038,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     bestT   = RTX_INF;
                     best    = HIT_MISS;
                     curRef  = S.leaf_ref[idx];
+                    if (nd.x > 1u) curRef2 = S.leaf_ref[idx + 1];
                 } else {
                     pop = true; // empty leaf: no hit here
                 }
@@ -1064,36 +1071,47 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                 tMax = both ? tMaxN : tMax;
             }
         } else if (doLeaf && state == ST_LEAF) {
-            const uint32_t r = curRef;
-            if (leafPos + 1 < leafEnd) curRef = S.leaf_ref[leafPos + 1]; // next reference in flight
-            if (COUNT) vis.prim++;
-            float t, u = 0.0f, v = 0.0f;
-            bool  hit;
-            if (r & RTX_REF_SPHERE) {
-                hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
+            // Two primitives of the leaf per step (when two are left and both are triangles): the pair goes through
+            // the packed test, one vector instruction for both (Triangle_HitAt2); results are taken in list order.
+            const uint32_t r0 = curRef, r1 = curRef2;
+            const bool     sph  = (r0 & RTX_REF_SPHERE) != 0u;
+            const bool     pair = leafPos + 1 < leafEnd && !sph && !(r1 & RTX_REF_SPHERE);
+            const uint32_t step = pair ? 2u : 1u;
+            if (leafPos + step < leafEnd) curRef = S.leaf_ref[leafPos + step]; // next references in flight
+            if (leafPos + step + 1 < leafEnd) curRef2 = S.leaf_ref[leafPos + step + 1];
+            if (COUNT) vis.prim += step;
+            if (sph) {
+                float t;
+                if (Sphere_HitAt(S.sph[r0 & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t) && t < bestT) bestT = t, best = r0, bu = 0.0f, bv = 0.0f;
             } else {
-                const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
-                float4        a  = tp[0];
+                const float4* tpA = S.tri + (uint64_t)TRI_STRIDE * r0;
+                const float4* tpB = S.tri + (uint64_t)TRI_STRIDE * (pair ? r1 : r0);
+                float4        aA = tpA[0], aB = tpB[0];
 #if TRI_WAIT
                 // One L2 request per triangle instead of three: a vector-L1 miss is not merged with a miss already
-                // pending on the same line (probe: tools/dbg/line.hip), and this kernel's bounce passes are bound by
-                // the number of L2 requests.  So take the first 16 bytes, wait, and read the rest from L1.
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)::"memory");
+                // pending on the same line (probe: tools/dbg/line.hip).  So take the first 16 bytes, wait, and read
+                // the rest from L1.
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(aA.x), "+v"(aA.y), "+v"(aA.z), "+v"(aA.w), "+v"(aB.x), "+v"(aB.y), "+v"(aB.z), "+v"(aB.w)::"memory");
 #endif
-                const float4 b  = tp[1];
-                const float  cx = *(const float*)(tp + 2); // 36 bytes of the record are used
-                hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cx), o, d, RT_EPSILON, tMax, t, u, v);
+                const float4 bA = tpA[1], bB = tpB[1];
+                const float  cA = *(const float*)(tpA + 2), cB = *(const float*)(tpB + 2); // 36 bytes of a record are used
+                bool         hit[2];
+                float        t[2], u[2], v[2];
+                Triangle_HitAt2(f3x2{f2v{aA.x, aB.x}, f2v{aA.y, aB.y}, f2v{aA.z, aB.z}}, f3x2{f2v{aA.w, aB.w}, f2v{bA.x, bB.x}, f2v{bA.y, bB.y}},
+                                f3x2{f2v{bA.z, bB.z}, f2v{bA.w, bB.w}, f2v{cA, cB}}, o, d, RT_EPSILON, tMax, hit, t, u, v);
+                if (hit[0] && t[0] < bestT) bestT = t[0], best = r0, bu = u[0], bv = v[0]; // strict: first in list wins ties (kdtree.c:485)
+                if (pair && hit[1] && t[1] < bestT) bestT = t[1], best = r1, bu = u[1], bv = v[1];
             }
-            if (hit && t < bestT) { // strict: first in list wins ties (kdtree.c:485)
-                bestT = t;
-                best  = r;
-                bu    = u;
-                bv    = v;
-            }
-            if (++leafPos == leafEnd) {
+            leafPos += step;
+            if (leafPos == leafEnd) {
                 if (best != HIT_MISS) fin = true; // a leaf that reports a hit ends the walk
                 else pop = true;
             }
+        }
+        if (COUNT) {
+            const uint32_t np = (uint32_t)__popcll(__ballot(pop)), nf = (uint32_t)__popcll(__ballot(fin));
+            if (np) ws[5]++, ws[6] += np;
+            if (nf) ws[7]++;
         }
         if (pop) {
             if (sp > 0) {
@@ -1125,7 +1143,11 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             state = ST_IDLE;
         }
     }
-    if (COUNT) add_visits(counters, vis);
+    if (COUNT) {
+        add_visits(counters, vis);
+        if (lane == 0)
+            for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&counters[8 + i], (unsigned long long)ws[i]);
+    }
 }
 
 // Material_Bounce for every ray of the queue + compaction of the survivors into `qout`
@@ -1803,10 +1825,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         (s.kind == 0 ? local.ms_raygen : s.kind == 1 ? local.ms_trace : s.kind == 2 ? local.ms_shade : s.kind == 3 ? local.ms_resolve : local.ms_sort) += ms;
         if (s.kind == 1) local.ms_trace_at_depth[s.depth] += ms;
     }
-    uint64_t c[5];
+    uint64_t c[16];
     HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
     local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2], local.visits_culled = c[3];
     local.hits_shaded  = c[4];
+    for (int i = 0; i < 8; i++) local.wave_stats[i] = c[8 + i];
     if (stats) *stats = local;
     return RTX_OK;
 }

@@ -275,6 +275,37 @@ DEV bool Triangle_HitAt(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tMin, float tMax,
     return true;
 }
 
+// Triangle_HitAt for two triangles A and B against the same ray, component 0 = A, component 1 = B.  Every
+// arithmetic operation is the one of the scalar routine above, in the same order, on a 2-vector: gfx950 issues
+// v_pk_mul_f32 / v_pk_add_f32 (two IEEE binary32 results per lane and instruction, no fusion with
+// -ffp-contract=off), so each component is bit-identical to a scalar call while the closest-hit kernel, which is
+// VALU-issue bound, pays one instruction for both.  The three divisions stay scalar (IEEE-correct sequences).
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct f3x2 {
+    f2v x, y, z;
+};
+DEV f3x2 cross2(f3x2 a, f3x2 b) { return f3x2{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV f2v  dot2(f3x2 a, f3x2 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV f3x2 bcast2(f3 v) { return f3x2{f2v{v.x, v.x}, f2v{v.y, v.y}, f2v{v.z, v.z}}; }
+
+DEV void Triangle_HitAt2(f3x2 v0, f3x2 e1, f3x2 e2, f3 o, f3 d, float tMin, float tMax, bool hit[2], float t[2], float u[2], float v[2])
+{
+    const f3x2 D = bcast2(d), O = bcast2(o);
+    const f3x2 h = cross2(D, e2);
+    const f2v  a = dot2(e1, h);
+    const f3x2 s = f3x2{O.x - v0.x, O.y - v0.y, O.z - v0.z};
+    const f2v  nu = dot2(s, h);
+    const f3x2 q  = cross2(s, e1);
+    const f2v  nv = dot2(D, q);
+    const f2v  nt = dot2(e2, q);
+#pragma unroll
+    for (int k = 0; k < 2; k++) { // the rejections of surfaces.c:146-165 as one predicate (NaNs fall through the same way)
+        const float uu = nu[k] / a[k], vv = nv[k] / a[k], tt = nt[k] / a[k];
+        hit[k] = !(fabsf(a[k]) < RT_EPSILON) && !(uu < 0.0f || uu > 1.0f) && !(vv < 0.0f || uu + vv > 1.0f) && !(tt > tMax || tt < tMin);
+        t[k] = tt, u[k] = uu, v[k] = vv;
+    }
+}
+
 DEV bool Sphere_HitAt(float4 sp, f3 o, f3 d, float tMin, float tMax, float& t) // :55
 {
     f3    c     = mk3(sp.x, sp.y, sp.z);

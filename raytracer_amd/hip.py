@@ -86,7 +86,8 @@ def device_count() -> int:
 
 
 def stats_dict(st: rtx_stats) -> dict:
-    d = {n: getattr(st, n) for n, _ in st._fields_ if n not in ("rays_at_depth", "ms_trace_at_depth")}
+    d = {n: getattr(st, n) for n, _ in st._fields_ if n not in ("rays_at_depth", "ms_trace_at_depth", "wave_stats")}
+    d["wave_stats"] = [int(x) for x in st.wave_stats]
     d["rays_at_depth"] = [int(x) for x in st.rays_at_depth if x]
     d["ms_trace_at_depth"] = [float(x) for x in st.ms_trace_at_depth][:len(d["rays_at_depth"])]
     return d

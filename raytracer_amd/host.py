@@ -140,7 +140,7 @@ class rtx_stats(C.Structure):
         ("hits_shaded", C.c_uint64), ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
         ("ms_raygen", C.c_double), ("ms_resolve", C.c_double), ("trace_launches", C.c_uint32), ("passes", C.c_uint32),
         ("ms_trace_at_depth", C.c_double * RTX_MAX_DEPTH),
-        ("visits_culled", C.c_uint64), ("ms_sort", C.c_double),
+        ("visits_culled", C.c_uint64), ("ms_sort", C.c_double), ("wave_stats", C.c_uint64 * 8),
     ]
 
 
