@@ -242,6 +242,15 @@ def test_error_paths(built_scenes, device_scenes):
     assert not acc.any() and st["rays_total"] == 0
 
 
+@pytest.mark.parametrize("scene", ["bunny", "pear", "materials"])
+def test_literal_and_culled_walks_render_the_same_frame(built_scenes, device_scenes, scene):
+    """Whole frames, all bounce depths: the culled walk (default) and the literal walk give the same f32 sums bit for bit."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    a = ds.render(sc.rtx_camera(), hip.make_params(240, 135, 4, 8, seed=(5, 6)))
+    b = ds.render(sc.rtx_camera(), hip.make_params(240, 135, 4, 8, seed=(5, 6), flags=hip.RTX_TRACE_LITERAL))
+    assert same_bits(a[1], b[1]) and np.array_equal(a[0], b[0]) and a[2]["rays_at_depth"] == b[2]["rays_at_depth"]
+
+
 def test_full_size_frame_properties(built_scenes, device_scenes):
     """BASELINE config 3 at full size (dragon stand-in, 1080p, 64 spp, depth 8; 341 M rays): properties that need
     no reference frame — two runs agree bit for bit although queue order is not deterministic (atomics in the
