@@ -403,6 +403,18 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         CullData cd;
         build_cull_data(d, cd);
         UP(upload(sc, cd.nodes16.data(), cd.nodes16.size(), &S.nodes16));
+        {
+            std::vector<uint4> n32(2 * (size_t)d->n_nodes, make_uint4(0, 0, 0, 0));
+            for (uint32_t i = 0; i < d->n_nodes; i++) {
+                const uint4 me = cd.nodes16[i];
+                uint4       l = make_uint4(0, 0, 0, 0), r = l;
+                if ((me.y >> 30) != 3u) l = cd.nodes16[me.y & 0x3FFFFFFFu], r = cd.nodes16[i + 1]; // indices checked by validate_desc
+                n32[2 * (size_t)i]     = make_uint4(me.x, me.y, l.z, l.w);
+                n32[2 * (size_t)i + 1] = make_uint4(r.z, r.w, 0, 0);
+            }
+            UP(upload(sc, n32.data(), n32.size(), &S.nodes32));
+            S.root_q[0] = cd.nodes16[d->root_index].z, S.root_q[1] = cd.nodes16[d->root_index].w;
+        }
         for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_iscale[a] = cd.iscale[a];
         S.cull_ro2 = cd.ro2;
         S.cull_kt  = cd.kt;
@@ -924,6 +936,16 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     Visits   vis  = {0, 0, 0, 0};
     uint32_t ws[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // COUNT: iterations, INNER runs / lanes, LEAF runs / lanes, POP runs / lanes, FIN runs
 
+    // FIN: Scene_ClosestHit's merge with the unbounded list (scene.c:122-142) and the hit record
+    auto write_hit = [&](uint32_t ref, float tH, float uH, float vH) {
+        if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
+        if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f;
+        hits[0 * hstride + ridx] = ref;
+        hits[1 * hstride + ridx] = __float_as_uint(tH);
+        hits[2 * hstride + ridx] = __float_as_uint(uH);
+        hits[3 * hstride + ridx] = __float_as_uint(vH);
+    };
+
     for (;;) {
         const uint64_t idle  = __ballot(state == ST_IDLE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
@@ -990,6 +1012,12 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     sp    = 0;
                     base  = 0;
                     state = ST_INNER;
+                    if (CULL && cullOK && box_missed(S, S.root_q[0], S.root_q[1], o, inv, RTX_INF)) {
+                        // the ray misses the box of everything in the tree: finished here, the lane stays free
+                        if (COUNT) vis.culled++;
+                        write_hit(HIT_MISS, RTX_INF, 0.0f, 0.0f);
+                        state = ST_IDLE;
+                    }
                 }
                 next += take;
             }
@@ -1006,30 +1034,18 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             if (doLeaf && nL) ws[3]++, ws[4] += nL;
         }
         if (doInner && state == ST_INNER) {
-            uint2 nd;
-            bool  culled = false;
+            uint2    nd;
+            uint32_t qL0 = 0, qL1 = 0, qR0 = 0, qR1 = 0; // CULL: boxes of the left and right child
             if (CULL) {
-                const uint4 q = S.nodes16[node];
-                nd            = make_uint2(q.x, q.y);
-                // slab test of the segment [0, kt * tMax] against the subtree's conservative box (grid → world: one fma)
-                const float bx0 = fmaf((float)(q.z & 0x7FFu), S.cull_scale[0], S.cull_lo[0]), bx1 = fmaf((float)(q.w & 0x7FFu), S.cull_scale[0], S.cull_lo[0]);
-                const float by0 = fmaf((float)((q.z >> 11) & 0x7FFu), S.cull_scale[1], S.cull_lo[1]), by1 = fmaf((float)((q.w >> 11) & 0x7FFu), S.cull_scale[1], S.cull_lo[1]);
-                const float bz0 = fmaf((float)(q.z >> 22), S.cull_scale[2], S.cull_lo[2]), bz1 = fmaf((float)(q.w >> 22), S.cull_scale[2], S.cull_lo[2]);
-                const float t1x = (bx0 - o.x) * inv.x, t2x = (bx1 - o.x) * inv.x;
-                const float t1y = (by0 - o.y) * inv.y, t2y = (by1 - o.y) * inv.y;
-                const float t1z = (bz0 - o.z) * inv.z, t2z = (bz1 - o.z) * inv.z;
-                const float tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
-                const float tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * S.cull_kt));
-                culled          = cullOK && q.z != 0xFFFFFFFFu && tn > tf;
+                const uint4 q0 = S.nodes32[2ull * node], q1 = S.nodes32[2ull * node + 1];
+                nd             = make_uint2(q0.x, q0.y);
+                qL0 = q0.z, qL1 = q0.w, qR0 = q1.x, qR1 = q1.y;
             } else {
                 nd = S.nodes[node];
             }
             const uint32_t type = nd.y >> 30;
             const uint32_t idx  = nd.y & 0x3FFFFFFFu;
-            if (culled) {
-                if (COUNT) vis.culled++;
-                pop = true; // nothing below this node can report a hit for this ray
-            } else if (type == 3u) {
+            if (type == 3u) {
                 if (COUNT) vis.leaf++;
                 if (nd.x != 0u) {
                     state   = ST_LEAF;
@@ -1059,16 +1075,36 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                 const bool     ge      = oA >= split;           // :511, :544
                 const bool     tieSide = (oA + 100.0f * dA) >= split; // Ray_At(ray,100)[axis], :529-535
                 const bool     goRight = (!par && behind && oA == split) ? tieSide : ge;
-                if (both && tMaxN == tI) { // :551/:563 far child pending with the OUTER tMax
-                    if (sp - base == LDS_SLOTS) { // window full: the oldest resident entry goes to scratch
-                        stk[base] = lstk[(base & (LDS_SLOTS - 1)) * 64];
-                        base++;
-                    }
-                    lstk[(sp & (LDS_SLOTS - 1)) * 64] = make_uint2(goRight ? idx : right, __float_as_uint(tMax));
-                    sp++;
+                const bool     farPending = both && tMaxN == tI; // :551/:563 far child, with the OUTER tMax
+                const float    tNear      = both ? tMaxN : tMax;
+                const uint32_t nearNode = goRight ? right : idx, farNode = goRight ? idx : right;
+                bool           missNear = false, missFar = false;
+                if (CULL) {
+                    // both children's boxes against the segments they would be walked with; a child the ray cannot
+                    // reach is neither fetched nor pushed
+                    bool miss[2];
+                    box_missed2(S, qL0, qL1, qR0, qR1, o, inv, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
+                    missNear = cullOK && (goRight ? miss[1] : miss[0]);
+                    missFar  = cullOK && (goRight ? miss[0] : miss[1]);
+                    if (COUNT) vis.culled += (missNear ? 1u : 0u) + (farPending && missFar ? 1u : 0u);
                 }
-                node = goRight ? right : idx;
-                tMax = both ? tMaxN : tMax;
+                const bool pushFar = farPending && !missFar;
+                if (!missNear) {
+                    if (pushFar) {
+                        if (sp - base == LDS_SLOTS) { // window full: the oldest resident entry goes to scratch
+                            stk[base] = lstk[(base & (LDS_SLOTS - 1)) * 64];
+                            base++;
+                        }
+                        lstk[(sp & (LDS_SLOTS - 1)) * 64] = make_uint2(farNode, __float_as_uint(tMax));
+                        sp++;
+                    }
+                    node = nearNode;
+                    tMax = tNear;
+                } else if (pushFar) { // near side unreachable: straight to the far side (outer tMax stays)
+                    node = farNode;
+                } else {
+                    pop = true;
+                }
             }
         } else if (doLeaf && state == ST_LEAF) {
             // Two primitives of the leaf per step (when two are left and both are triangles): the pair goes through
@@ -1132,14 +1168,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             }
         }
         if (fin) {
-            uint32_t ref = best;
-            float    tH = bestT, uH = bu, vH = bv;
-            if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
-            if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f; // scene.c:122-142
-            hits[0 * hstride + ridx] = ref;
-            hits[1 * hstride + ridx] = __float_as_uint(tH);
-            hits[2 * hstride + ridx] = __float_as_uint(uH);
-            hits[3 * hstride + ridx] = __float_as_uint(vH);
+            write_hit(best, bestT, bu, bv);
             state = ST_IDLE;
         }
     }

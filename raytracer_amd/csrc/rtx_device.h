@@ -39,6 +39,11 @@ struct SceneDev {
     // (k_trace_flat<.., CULL>), 16 B per node:  {w0, w1, qmin, qmax},  q = x | y << 11 | z << 22 on the grid
     // cull_lo + q * cull_scale (2047 x 2047 x 1023 steps); qmin = 0xFFFFFFFF: never cull this node
     const uint4*    nodes16;
+    // culled kernel: 32 B per node, the node and the boxes of BOTH children, so that a child the ray cannot reach
+    // is never fetched:  [0] = {w0, w1, qmin(left), qmax(left)}  [1] = {qmin(right), qmax(right), 0, 0};
+    // left child = index in w1, right child = node + 1; the root's own box is root_q
+    const uint4*    nodes32;
+    uint32_t        root_q[2];
     float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
     float           cull_lo[3], cull_scale[3], cull_iscale[3];
@@ -303,6 +308,47 @@ DEV void Triangle_HitAt2(f3x2 v0, f3x2 e1, f3x2 e2, f3 o, f3 d, float tMin, floa
         const float uu = nu[k] / a[k], vv = nv[k] / a[k], tt = nt[k] / a[k];
         hit[k] = !(fabsf(a[k]) < RT_EPSILON) && !(uu < 0.0f || uu > 1.0f) && !(vv < 0.0f || uu + vv > 1.0f) && !(tt > tMax || tt < tMin);
         t[k] = tt, u[k] = uu, v[k] = vv;
+    }
+}
+
+// Conservative box tests of the culled walk (not part of the reference).  Does the segment
+// {o + t d, 0 <= t <= kt * tMax} miss the quantised box (qmin, qmax)?  grid → world is one fma per plane; `inv` is
+// 1/d with infinities replaced by +-3e38.  The two-box form tests both children of a node at once with packed
+// math: component 0 = left child, 1 = right child (oracle/oracle.cpp replays the same operations).
+DEV bool box_missed(const SceneDev& S, uint32_t qmin, uint32_t qmax, f3 o, f3 inv, float tMax)
+{
+    const float bx0 = fmaf((float)(qmin & 0x7FFu), S.cull_scale[0], S.cull_lo[0]), bx1 = fmaf((float)(qmax & 0x7FFu), S.cull_scale[0], S.cull_lo[0]);
+    const float by0 = fmaf((float)((qmin >> 11) & 0x7FFu), S.cull_scale[1], S.cull_lo[1]), by1 = fmaf((float)((qmax >> 11) & 0x7FFu), S.cull_scale[1], S.cull_lo[1]);
+    const float bz0 = fmaf((float)(qmin >> 22), S.cull_scale[2], S.cull_lo[2]), bz1 = fmaf((float)(qmax >> 22), S.cull_scale[2], S.cull_lo[2]);
+    const float t1x = (bx0 - o.x) * inv.x, t2x = (bx1 - o.x) * inv.x;
+    const float t1y = (by0 - o.y) * inv.y, t2y = (by1 - o.y) * inv.y;
+    const float t1z = (bz0 - o.z) * inv.z, t2z = (bz1 - o.z) * inv.z;
+    const float tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    const float tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * S.cull_kt));
+    return qmin != 0xFFFFFFFFu && tn > tf;
+}
+
+DEV void box_missed2(const SceneDev& S, uint32_t qminL, uint32_t qmaxL, uint32_t qminR, uint32_t qmaxR, f3 o, f3 inv, f2v tMax, bool miss[2])
+{
+    const f2v sx = f2v{S.cull_scale[0], S.cull_scale[0]}, sy = f2v{S.cull_scale[1], S.cull_scale[1]}, sz = f2v{S.cull_scale[2], S.cull_scale[2]};
+    const f2v lx = f2v{S.cull_lo[0], S.cull_lo[0]}, ly = f2v{S.cull_lo[1], S.cull_lo[1]}, lz = f2v{S.cull_lo[2], S.cull_lo[2]};
+    const f2v ox = f2v{o.x, o.x}, oy = f2v{o.y, o.y}, oz = f2v{o.z, o.z};
+    const f2v ix = f2v{inv.x, inv.x}, iy = f2v{inv.y, inv.y}, iz = f2v{inv.z, inv.z};
+    const f2v bx0 = __builtin_elementwise_fma(f2v{(float)(qminL & 0x7FFu), (float)(qminR & 0x7FFu)}, sx, lx);
+    const f2v bx1 = __builtin_elementwise_fma(f2v{(float)(qmaxL & 0x7FFu), (float)(qmaxR & 0x7FFu)}, sx, lx);
+    const f2v by0 = __builtin_elementwise_fma(f2v{(float)((qminL >> 11) & 0x7FFu), (float)((qminR >> 11) & 0x7FFu)}, sy, ly);
+    const f2v by1 = __builtin_elementwise_fma(f2v{(float)((qmaxL >> 11) & 0x7FFu), (float)((qmaxR >> 11) & 0x7FFu)}, sy, ly);
+    const f2v bz0 = __builtin_elementwise_fma(f2v{(float)(qminL >> 22), (float)(qminR >> 22)}, sz, lz);
+    const f2v bz1 = __builtin_elementwise_fma(f2v{(float)(qmaxL >> 22), (float)(qmaxR >> 22)}, sz, lz);
+    const f2v t1x = (bx0 - ox) * ix, t2x = (bx1 - ox) * ix;
+    const f2v t1y = (by0 - oy) * iy, t2y = (by1 - oy) * iy;
+    const f2v t1z = (bz0 - oz) * iz, t2z = (bz1 - oz) * iz;
+    const f2v tk  = tMax * f2v{S.cull_kt, S.cull_kt};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float tn = fmaxf(fmaxf(fminf(t1x[k], t2x[k]), fminf(t1y[k], t2y[k])), fmaxf(fminf(t1z[k], t2z[k]), 0.0f));
+        const float tf = fminf(fminf(fmaxf(t1x[k], t2x[k]), fmaxf(t1y[k], t2y[k])), fminf(fmaxf(t1z[k], t2z[k]), tk[k]));
+        miss[k]        = (k == 0 ? qminL : qminR) != 0xFFFFFFFFu && tn > tf;
     }
 }
 
