@@ -193,12 +193,12 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
 int rtx_scene_destroy(rtx_scene* scene);
 int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
 /* Parity seam for the culled walk (host only, needs no device): the conservative, quantised subtree
- * boxes rtx_scene_create uploads — qbox2: n_nodes x {qmin, qmax}, q = x | y << 11 | z << 22 on the grid
- * lo + q * scale, qmin = 0xFFFFFFFF meaning "never cull" — and info14 = {centre xyz, origin radius^2,
- * tMax stretch, lo xyz, scale xyz, 1/scale xyz}, so that a CPU checker can replay the very same culling
- * decisions.  No counterpart in the reference (its KDTree.worldBox, kdtree.c:435, is never used by the
- * traversal). */
-int rtx_cull_data_build(const rtx_scene_desc* desc, uint32_t* qbox2, float* info14);
+ * boxes rtx_scene_create uploads — qbox6: n_nodes x {min x y z, max x y z} as 16-bit steps of the grid
+ * lo + q * scale (min.x = 0xFFFF with max.x = 0 meaning "never cull") — and info14 = {centre xyz, origin
+ * radius^2, tMax stretch, lo xyz, scale xyz, magic xyz}, where the device decodes a coordinate as
+ * fma(2^23 + q, scale, magic), so that a CPU checker can replay the very same culling decisions.  No
+ * counterpart in the reference (its KDTree.worldBox, kdtree.c:435, is never used by the traversal). */
+int rtx_cull_data_build(const rtx_scene_desc* desc, uint16_t* qbox6, float* info14);
 
 /* ---- ray-level parity seam: batched Scene_ClosestHit (src/world/scene.h:12).
  * Host pointers, interleaved xyz.  dir need not be normalised: Ray_Make (src/rt/ray.c:3-16)

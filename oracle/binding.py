@@ -31,7 +31,7 @@ def lib():
         f32p, u32p, u8p, u64p = (C.POINTER(t) for t in (C.c_float, C.c_uint32, C.c_uint8, C.c_uint64))
         dp = C.POINTER(rtx_scene_desc)
         L.oracle_trace.argtypes = [dp, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
-        L.oracle_trace_culled.argtypes = [dp, u32p, f32p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
+        L.oracle_trace_culled.argtypes = [dp, C.POINTER(C.c_uint16), f32p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
         L.oracle_render.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), f32p, u8p, u64p, C.c_int]
         L.oracle_camera_rays.argtypes = [C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
                                          f32p, f32p, u32p]
@@ -57,9 +57,9 @@ def trace(desc, origin, direction, unit_dir=False, cull=None):
                normal=np.empty((n, 3), np.float32), uv=np.empty((n, 2), np.float32), front=np.empty(n, np.uint8))
     vis = np.zeros(4 if cull is not None else 3, np.uint64)
     steps = np.zeros(n, np.uint32)
-    qbox = np.ascontiguousarray(cull[0], np.uint32) if cull is not None else None
+    qbox = np.ascontiguousarray(cull[0], np.uint16) if cull is not None else None
     info = np.ascontiguousarray(cull[1], np.float32) if cull is not None else None
-    rc = lib().oracle_trace_culled(desc, _p(qbox, C.c_uint32), _p(info, C.c_float), n, _p(o, C.c_float), _p(d, C.c_float), int(unit_dir), _p(out["prim_id"], C.c_uint32),
+    rc = lib().oracle_trace_culled(desc, _p(qbox, C.c_uint16), _p(info, C.c_float), n, _p(o, C.c_float), _p(d, C.c_float), int(unit_dir), _p(out["prim_id"], C.c_uint32),
                             _p(out["t"], C.c_float), _p(out["position"], C.c_float), _p(out["normal"], C.c_float),
                             _p(out["uv"], C.c_float), _p(out["front"], C.c_uint8), _p(vis, C.c_uint64),
                             _p(steps, C.c_uint32))

@@ -264,12 +264,12 @@ static void HitInfo_SetFaceNormal(HitInfo* hit, const Ray* ray, vec3 outwardNorm
 // ---- scene view over the flattened pools ----
 // Checker for the GPU's subtree-box culling (NOT part of the reference): when `qbox` is
 // set, CheckHitNextNode skips a node whose box the segment [0, kt*tMax] of the ray misses — with the
-// device's own boxes (rtx_scene_cull_data) and the device's own test, operation for operation.
+// device's own boxes (rtx_cull_data_build) and the device's own test, operation for operation.
 struct Cull {
-    const uint32_t* qbox; // 2 words per node: qmin, qmax (x | y << 11 | z << 22); qmin = 0xFFFFFFFF: never cull
+    const uint16_t* qbox; // 6 per node: min x y z, max x y z on the 16-bit grid; min.x = 0xFFFF, max.x = 0: never cull
     vec3            c;
     f32             ro2, kt;
-    vec3            lo, scale, iscale;
+    vec3            lo, scale, magic; // coordinate = fma(2^23 + q, scale, magic)
     // per ray
     bool ok;
     vec3 o, inv; // origin, and 1/dir with infinities replaced by +-3e38
@@ -295,18 +295,26 @@ static void cull_begin_ray(Cull* c, const Ray* ray)
     c->ok        = r2 <= c->ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
 }
 
+static inline f32 box_coord(u32 q, f32 scale, f32 magic)
+{
+    const u32 bits = 0x4B000000u | q; // the float 2^23 + q, exactly
+    f32       f;
+    memcpy(&f, &bits, 4);
+    return fmaf(f, scale, magic);
+}
+
 static bool cull_node(const Cull* c, u32 node, f32 tMax)
 {
-    const u32 qz = c->qbox[2ull * node], qw = c->qbox[2ull * node + 1];
-    const f32 bx0 = fmaf((f32)(qz & 0x7FFu), c->scale.x, c->lo.x), bx1 = fmaf((f32)(qw & 0x7FFu), c->scale.x, c->lo.x);
-    const f32 by0 = fmaf((f32)((qz >> 11) & 0x7FFu), c->scale.y, c->lo.y), by1 = fmaf((f32)((qw >> 11) & 0x7FFu), c->scale.y, c->lo.y);
-    const f32 bz0 = fmaf((f32)(qz >> 22), c->scale.z, c->lo.z), bz1 = fmaf((f32)(qw >> 22), c->scale.z, c->lo.z);
+    const uint16_t* q = c->qbox + 6ull * node;
+    const f32 bx0 = box_coord(q[0], c->scale.x, c->magic.x), bx1 = box_coord(q[3], c->scale.x, c->magic.x);
+    const f32 by0 = box_coord(q[1], c->scale.y, c->magic.y), by1 = box_coord(q[4], c->scale.y, c->magic.y);
+    const f32 bz0 = box_coord(q[2], c->scale.z, c->magic.z), bz1 = box_coord(q[5], c->scale.z, c->magic.z);
     const f32 t1x = (bx0 - c->o.x) * c->inv.x, t2x = (bx1 - c->o.x) * c->inv.x;
     const f32 t1y = (by0 - c->o.y) * c->inv.y, t2y = (by1 - c->o.y) * c->inv.y;
     const f32 t1z = (bz0 - c->o.z) * c->inv.z, t2z = (bz1 - c->o.z) * c->inv.z;
     const f32 tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
     const f32 tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
-    return c->ok && qz != 0xFFFFFFFFu && tn > tf;
+    return c->ok && !(q[0] == 0xFFFFu && q[3] == 0u) && tn > tf;
 }
 
 struct Prim { // what the reference calls Object*: a pool reference
@@ -1157,20 +1165,20 @@ extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o
     return oracle_trace_culled(desc, NULL, NULL, n, o, dxyz, unit_dir, pid, t, pos, nrm, uv, front, visits3, steps_per_ray);
 }
 
-extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint32_t* qbox2, const float* info14, size_t n, const float* o,
+extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, size_t n, const float* o,
                                    const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
                                    uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
     Scene sc = {desc, 0, 0, 0, NULL, 0};
     Cull  cull;
-    if (qbox2) {
-        cull.qbox   = qbox2;
+    if (qbox6) {
+        cull.qbox   = qbox6;
         cull.c      = vec(info14[0], info14[1], info14[2]);
         cull.ro2    = info14[3];
         cull.kt     = info14[4];
         cull.lo     = vec(info14[5], info14[6], info14[7]);
         cull.scale  = vec(info14[8], info14[9], info14[10]);
-        cull.iscale = vec(info14[11], info14[12], info14[13]);
+        cull.magic  = vec(info14[11], info14[12], info14[13]);
         sc.cull     = &cull;
     }
     for (size_t i = 0; i < n; i++) {
@@ -1194,7 +1202,7 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint32_t* q
     }
     if (visits3) {
         visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
-        if (qbox2) visits3[3] = sc.nCulled; // 4 counters in checker mode
+        if (qbox6) visits3[3] = sc.nCulled; // 4 counters in checker mode
     }
     return 0;
 }

@@ -210,14 +210,11 @@ static int validate_desc(const rtx_scene_desc* d)
 // its rounding equals a displacement of the box plane by <= 3 eps |b - o| <= 6 eps D, covered by 32 eps D.
 // ---------------------------------------------------------------------------------------------
 struct CullData {
-    std::vector<uint4> nodes16; // {w0, w1, qmin, qmax}
-    float              c[3], ro2, kt;
-    float              lo[3], scale[3], iscale[3]; // quantisation grid: x = lo + q * scale
-    bool               useful;                     // median triangle pad below its own size
+    std::vector<uint16_t> q16; // 6 per node: min x y z, max x y z on the grid; min.x = 0xFFFF, max.x = 0: never cull
+    float                 c[3], ro2, kt;
+    float                 lo[3], scale[3], magic[3]; // grid: x = lo + q * scale = fma(2^23 + q, scale, magic)
+    bool                  useful;                    // median triangle pad below its own size
 };
-#define CULL_QBITS_X 11
-#define CULL_QBITS_Y 11
-#define CULL_QBITS_Z 10
 
 static float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
 static float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
@@ -311,59 +308,61 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
             for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * l + a], blo[3 * r + a]), bhi[3 * n + a] = std::max(bhi[3 * l + a], bhi[3 * r + a]);
         }
     }
-    // Quantise to 11/11/10 bits per axis on a grid over all finite boxes (+2 steps of margin on every side).
-    // Box minima round down and maxima round up, one further step outward absorbs the binary32 rounding of
-    // the kernel's transform of the ray into grid units ((o - lo) * iscale, error << 1 step for |o| within
-    // the culling radius).  A node with an unbounded box is marked "never cull".
+    // Quantise to 16 bits per axis on a grid over all finite boxes (+3 steps of margin on every side).  The kernel
+    // decodes a coordinate with ONE integer instruction and the fma it needs anyway: the 16-bit value is OR-ed into
+    // the mantissa of 2^23 (= 0x4B000000), which is the float 2^23 + q exactly, and x = fma(2^23 + q, scale, magic)
+    // with magic = fl(lo - 2^23 * scale).  The grid origin used for quantising is therefore lo_eff = magic + 2^23 * scale
+    // (exact in double), so that decoded planes are lo_eff + q * scale up to the one rounding of the fma (<= 1 ulp of
+    // the coordinate).  Box minima round down and maxima round up, plus one further step outward.  A node with an
+    // unbounded box is marked "never cull".
     double glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t k = 0; k < 3 * (T + Sn); k++)
         if (std::isfinite(plo[k]) && std::isfinite(phi[k])) glo[k % 3] = std::min(glo[k % 3], plo[k]), ghi[k % 3] = std::max(ghi[k % 3], phi[k]);
-    const int levels[3] = {(1 << CULL_QBITS_X) - 1, (1 << CULL_QBITS_Y) - 1, (1 << CULL_QBITS_Z) - 1};
-    double    scale[3];
+    const double LEVELS = 65535.0, TWO23 = 8388608.0;
+    double       scale[3];
     for (int a = 0; a < 3; a++) {
         if (!(glo[a] <= ghi[a])) glo[a] = 0.0, ghi[a] = 1.0; // no finite box at all
-        double ext = std::max(ghi[a] - glo[a], 1e-6);
-        scale[a]   = ext / (levels[a] - 4);
-        glo[a] -= 2.0 * scale[a];
-        out.lo[a]     = (float)glo[a];
-        out.scale[a]  = (float)scale[a];
-        out.iscale[a] = (float)(1.0 / scale[a]);
-        glo[a]        = (double)out.lo[a]; // quantise against the values the kernel will use
-        scale[a]      = (double)out.scale[a];
+        const double ext = std::max(ghi[a] - glo[a], 1e-6);
+        out.scale[a]     = (float)(ext / (LEVELS - 8.0));
+        scale[a]         = (double)out.scale[a];
+        out.magic[a]     = (float)(glo[a] - 4.0 * scale[a] - TWO23 * scale[a]);
+        glo[a]           = (double)out.magic[a] + TWO23 * scale[a]; // the origin the kernel's decode implies
+        out.lo[a]        = (float)glo[a];
     }
-    out.nodes16.resize(N);
+    out.q16.assign(6 * N, 0);
     for (size_t n = 0; n < N; n++) {
-        uint32_t q[2][3];
-        bool     nocull = false;
+        uint16_t* q      = &out.q16[6 * n];
+        bool      nocull = false;
         for (int a = 0; a < 3; a++) {
             const double l = blo[3 * n + a], h = bhi[3 * n + a];
-            if (!(l <= h)) { // node never reached from the root, or an empty leaf (handled by its len == 0)
-                q[0][a] = q[1][a] = 0;
-                continue;
-            }
+            if (!(l <= h)) continue; // node never reached from the root, or an empty leaf (handled by its len == 0)
             if (!std::isfinite(l) || !std::isfinite(h)) {
                 nocull = true;
                 continue;
             }
             const double ql = floor((l - glo[a]) / scale[a]) - 1.0, qh = ceil((h - glo[a]) / scale[a]) + 1.0;
-            q[0][a] = (uint32_t)std::min<double>(std::max(ql, 0.0), levels[a]);
-            q[1][a] = (uint32_t)std::min<double>(std::max(qh, 0.0), levels[a]);
+            q[a]     = (uint16_t)std::min<double>(std::max(ql, 0.0), LEVELS);
+            q[3 + a] = (uint16_t)std::min<double>(std::max(qh, 0.0), LEVELS);
         }
-        const uint32_t qmin = nocull ? 0xFFFFFFFFu : (q[0][0] | q[0][1] << CULL_QBITS_X | q[0][2] << (CULL_QBITS_X + CULL_QBITS_Y));
-        const uint32_t qmax = nocull ? 0u : (q[1][0] | q[1][1] << CULL_QBITS_X | q[1][2] << (CULL_QBITS_X + CULL_QBITS_Y));
-        out.nodes16[n]      = make_uint4(d->node_w0[n], d->node_w1[n], qmin, qmax);
+        if (nocull) q[0] = 0xFFFF, q[3] = 0;
     }
 }
 
-extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint32_t* qbox2, float* info14)
+// a box as the kernel reads it: {x, y, z}, max << 16 | min
+static void pack_box(const uint16_t* q, uint32_t w[3])
 {
-    if (!qbox2 || !info14) return fail(RTX_E_INVALID, "null argument");
+    for (int a = 0; a < 3; a++) w[a] = (uint32_t)q[3 + a] << 16 | q[a];
+}
+
+extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint16_t* qbox6, float* info14)
+{
+    if (!qbox6 || !info14) return fail(RTX_E_INVALID, "null argument");
     int rc = validate_desc(d);
     if (rc != RTX_OK) return rc;
     CullData cd;
     build_cull_data(d, cd);
-    for (size_t n = 0; n < d->n_nodes; n++) qbox2[2 * n] = cd.nodes16[n].z, qbox2[2 * n + 1] = cd.nodes16[n].w;
-    for (int a = 0; a < 3; a++) info14[a] = cd.c[a], info14[5 + a] = cd.lo[a], info14[8 + a] = cd.scale[a], info14[11 + a] = cd.iscale[a];
+    memcpy(qbox6, cd.q16.data(), cd.q16.size() * sizeof(uint16_t));
+    for (int a = 0; a < 3; a++) info14[a] = cd.c[a], info14[5 + a] = cd.lo[a], info14[8 + a] = cd.scale[a], info14[11 + a] = cd.magic[a];
     info14[3] = cd.ro2;
     info14[4] = cd.kt;
     return RTX_OK;
@@ -402,24 +401,24 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     {
         CullData cd;
         build_cull_data(d, cd);
-        UP(upload(sc, cd.nodes16.data(), cd.nodes16.size(), &S.nodes16));
         {
             std::vector<uint4> n32(2 * (size_t)d->n_nodes, make_uint4(0, 0, 0, 0));
             for (uint32_t i = 0; i < d->n_nodes; i++) {
-                const uint4 me = cd.nodes16[i];
-                uint4       l = make_uint4(0, 0, 0, 0), r = l;
-                if ((me.y >> 30) != 3u) l = cd.nodes16[me.y & 0x3FFFFFFFu], r = cd.nodes16[i + 1]; // indices checked by validate_desc
-                n32[2 * (size_t)i]     = make_uint4(me.x, me.y, l.z, l.w);
-                n32[2 * (size_t)i + 1] = make_uint4(r.z, r.w, 0, 0);
+                uint32_t l[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+                if ((d->node_w1[i] >> 30) != 3u) { // indices checked by validate_desc
+                    pack_box(&cd.q16[6 * (size_t)(d->node_w1[i] & 0x3FFFFFFFu)], l);
+                    pack_box(&cd.q16[6 * ((size_t)i + 1)], r);
+                }
+                n32[2 * (size_t)i]     = make_uint4(d->node_w0[i], d->node_w1[i], l[0], l[1]);
+                n32[2 * (size_t)i + 1] = make_uint4(l[2], r[0], r[1], r[2]);
             }
             UP(upload(sc, n32.data(), n32.size(), &S.nodes32));
-            S.root_q[0] = cd.nodes16[d->root_index].z, S.root_q[1] = cd.nodes16[d->root_index].w;
+            pack_box(&cd.q16[6 * (size_t)d->root_index], S.root_q);
         }
-        for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_iscale[a] = cd.iscale[a];
+        for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_magic[a] = cd.magic[a];
         S.cull_ro2 = cd.ro2;
         S.cull_kt  = cd.kt;
-        const int lv[3] = {(1 << CULL_QBITS_X) - 1, (1 << CULL_QBITS_Y) - 1, (1 << CULL_QBITS_Z) - 1};
-        for (int a = 0; a < 3; a++) S.bin_inv[a] = (float)(1 << BIN_CELL_BITS) / (cd.scale[a] * (float)lv[a]); // cells over the box grid
+        for (int a = 0; a < 3; a++) S.bin_inv[a] = (float)(1 << BIN_CELL_BITS) / (cd.scale[a] * 65535.0f); // cells over the box grid
         sc->cull_useful = cd.useful;
     }
     {
@@ -1012,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     sp    = 0;
                     base  = 0;
                     state = ST_INNER;
-                    if (CULL && cullOK && box_missed(S, S.root_q[0], S.root_q[1], o, inv, RTX_INF)) {
+                    if (CULL && cullOK && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o, inv, RTX_INF)) {
                         // the ray misses the box of everything in the tree: finished here, the lane stays free
                         if (COUNT) vis.culled++;
                         write_hit(HIT_MISS, RTX_INF, 0.0f, 0.0f);
@@ -1035,11 +1034,10 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
         }
         if (doInner && state == ST_INNER) {
             uint2    nd;
-            uint32_t qL0 = 0, qL1 = 0, qR0 = 0, qR1 = 0; // CULL: boxes of the left and right child
+            uint4    qa = make_uint4(0, 0, 0, 0), qb = qa; // CULL: {w0, w1, L.x, L.y}, {L.z, R.x, R.y, R.z}: the children's boxes
             if (CULL) {
-                const uint4 q0 = S.nodes32[2ull * node], q1 = S.nodes32[2ull * node + 1];
-                nd             = make_uint2(q0.x, q0.y);
-                qL0 = q0.z, qL1 = q0.w, qR0 = q1.x, qR1 = q1.y;
+                qa = S.nodes32[2ull * node], qb = S.nodes32[2ull * node + 1];
+                nd = make_uint2(qa.x, qa.y);
             } else {
                 nd = S.nodes[node];
             }
@@ -1083,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     // both children's boxes against the segments they would be walked with; a child the ray cannot
                     // reach is neither fetched nor pushed
                     bool miss[2];
-                    box_missed2(S, qL0, qL1, qR0, qR1, o, inv, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
+                    box_missed2(S, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, o, inv, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
                     missNear = cullOK && (goRight ? miss[1] : miss[0]);
                     missFar  = cullOK && (goRight ? miss[0] : miss[1]);
                     if (COUNT) vis.culled += (missNear ? 1u : 0u) + (farPending && missFar ? 1u : 0u);

@@ -51,7 +51,7 @@ def lib() -> C.CDLL:
     sig("rtx_scene_create", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.POINTER(vp))
     sig("rtx_scene_destroy", C.c_int, vp)
     sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
-    sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), u32p, f32p)
+    sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), C.POINTER(C.c_uint16), f32p)
     sig("rtx_trace_closest", C.c_int, vp, C.c_size_t, f32p, f32p, u32p, f32p, f32p, f32p, f32p, u8p,
         C.POINTER(rtx_stats), C.c_uint32)
     sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
@@ -109,20 +109,24 @@ def make_params(width, height, spp, max_depth, seed=(1, 2), sample_range=None, b
 
 def cull_data(desc):
     """Quantised conservative subtree boxes + culling constants of a scene (host-side preprocessing of
-    librt_hip.so, no device needed): (qbox[n_nodes, 2] u32, info[14] f32), see rtx_cull_data_build."""
-    qbox = np.zeros((desc.contents.n_nodes, 2), np.uint32)
+    librt_hip.so, no device needed): (qbox[n_nodes, 6] u16, info[14] f32), see rtx_cull_data_build."""
+    qbox = np.zeros((desc.contents.n_nodes, 6), np.uint16)
     info = np.zeros(14, np.float32)
-    _check(lib().rtx_cull_data_build(desc, _p(qbox, C.c_uint32), _p(info, C.c_float)))
+    _check(lib().rtx_cull_data_build(desc, _p(qbox, C.c_uint16), _p(info, C.c_float)))
     return qbox, info
+
+
+def cull_never(qbox):
+    """nodes marked 'never cull' (unbounded box)"""
+    return (qbox[:, 0] == 0xFFFF) & (qbox[:, 3] == 0)
 
 
 def cull_boxes_world(qbox, info):
     """Decode (qbox, info) to world-space boxes [n, 6] (min xyz, max xyz); 'never cull' nodes come out infinite."""
-    lo, scale = info[5:8].astype(np.float64), info[8:11].astype(np.float64)
-    def un(q):
-        return np.stack([q & 0x7FF, (q >> 11) & 0x7FF, q >> 22], axis=1).astype(np.float64)
-    b = np.concatenate([lo + un(qbox[:, 0]) * scale, lo + un(qbox[:, 1]) * scale], axis=1)
-    never = qbox[:, 0] == 0xFFFFFFFF
+    scale, magic = info[8:11].astype(np.float64), info[11:14].astype(np.float64)
+    lo = magic + 8388608.0 * scale  # what fma(2^23 + q, scale, magic) decodes to at q = 0
+    b = np.concatenate([lo + qbox[:, :3].astype(np.float64) * scale, lo + qbox[:, 3:].astype(np.float64) * scale], axis=1)
+    never = cull_never(qbox)
     b[never, :3], b[never, 3:] = -np.inf, np.inf
     return b
 

@@ -109,4 +109,4 @@ def test_boxes_contain_their_primitives(built_scenes):
                 continue
             v = pos[:, r].reshape(3, 3)
             assert (v >= boxes[k, :3]).all() and (v <= boxes[k, 3:]).all()
-    assert info[4] >= 1.0 and info[3] > 0 and not (qbox[reach][:, 0] == 0xFFFFFFFF).any()
+    assert info[4] >= 1.0 and info[3] > 0 and not hip.cull_never(qbox[reach]).any()
