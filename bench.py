@@ -32,10 +32,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 def alg_bytes(vi, vl, vp, vc, rays):
     """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d), for the walk the kernel actually does
-    (subtree-box culling on): every node it fetches — inner, leaf, or fetched and culled — is the 8-B kd
-    node + its 8-B quantised box = 16 B; (4 B leaf ref + 36 B vertex positions) per primitive test;
-    64 B ray record read + 44 B hit record write per ray.  The N_* are the kernel's own counters."""
-    return 16 * (vi + vl + vc) + 40 * vp + (64 + 44) * rays
+    (subtree-box culling on): an inner node it visits is the 8-B kd node + the two 12-B boxes of its children
+    = 32 B, a leaf it visits 8 B (children whose box the ray misses are never fetched: vc only counts them);
+    (4 B leaf ref + 36 B vertex positions) per primitive test; 64 B ray record read + 44 B hit record write
+    per ray.  The N_* are the kernel's own counters."""
+    return 32 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
 
 
 def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):
@@ -177,7 +178,7 @@ def main():
                        "scene": args.scene, "triangles": int(sc.desc.contents.n_tris), "kd_nodes": int(sc.desc.contents.n_nodes),
                        "rays_per_frame": rays_frame, "rays_per_camera_path": rays_frame / (args.width * args.height * args.spp),
                        "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame,
-                                          "fetched_and_culled": v[12] / rays_frame},
+                                          "children_culled_unfetched": v[12] / rays_frame},
                        "kernel_ms_per_frame": {"trace": ms_trace / args.steps / world, "shade": v[9] / args.steps / world,
                                                "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world,
                                                "ray_binning": v[13] / args.steps / world}},
