@@ -84,7 +84,7 @@ struct rtx_scene {
     void*    ws;
     uint64_t ws_bytes;
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
-    unsigned persist_blocks[4]; // resident grid of the persistent kernels: [count + 2 * culled] (0 = not queried yet)
+    unsigned persist_blocks[8]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)] (0 = not queried yet)
 };
 
 static int workspace(rtx_scene* sc, uint64_t bytes, char** out)
@@ -896,7 +896,38 @@ DEV uint32_t xcc_id()
     return v & 7u;
 }
 
-template <bool COUNT, bool CULL>
+
+// ---- wave-wide scans through DPP (all 64 lanes must be active) ---------------------------------------------
+#define DPP_ADD(v, ctrl, rmask) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false))
+DEV uint32_t wave_scan_add(uint32_t v) // inclusive prefix sum over the lanes
+{
+    v = DPP_ADD(v, 0x111, 0xF); // row_shr:1
+    v = DPP_ADD(v, 0x112, 0xF); // row_shr:2
+    v = DPP_ADD(v, 0x114, 0xF); // row_shr:4
+    v = DPP_ADD(v, 0x118, 0xF); // row_shr:8
+    v = DPP_ADD(v, 0x142, 0xA); // row_bcast:15 into rows 1 and 3
+    v = DPP_ADD(v, 0x143, 0xC); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+#define DPP_MAX(v, ctrl, rmask)                                                          \
+    {                                                                                    \
+        const uint32_t w_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false); \
+        v                 = w_ > v ? w_ : v;                                             \
+    }
+DEV uint32_t wave_scan_max(uint32_t v) // inclusive prefix maximum over the lanes
+{
+    DPP_MAX(v, 0x111, 0xF);
+    DPP_MAX(v, 0x112, 0xF);
+    DPP_MAX(v, 0x114, 0xF);
+    DPP_MAX(v, 0x118, 0xF);
+    DPP_MAX(v, 0x142, 0xA);
+    DPP_MAX(v, 0x143, 0xC);
+    return v;
+}
+DEV float lane_read(float v, uint32_t src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)__float_as_uint(v))); }
+DEV uint32_t lane_read(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+
+template <bool COUNT, bool CULL, bool COOP>
 __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
                                                     uint32_t chunk, uint64_t* counters, uint32_t tune)
@@ -923,6 +954,13 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     // of stack lines alive and evicted the kd-tree from the 8 x 4 MB L2s (rocprof: TCC hit rate 50 %).
     __shared__ uint2 s_stk[4 * LDS_SLOTS * 64];
     uint2* const     lstk = s_stk + (threadIdx.x >> 6) * (LDS_SLOTS * 64) + lane;
+    // COOP: per wave, 64 owner slots {closest key (t bits << 32 | slot), winner's {ref, u, v}} and the slot -> owner map
+    __shared__ unsigned long long s_key[COOP ? 256 : 1];
+    __shared__ uint4              s_win[COOP ? 256 : 1];
+    __shared__ uint32_t           s_own[COOP ? 256 : 1];
+    unsigned long long* const     wkey = s_key + (COOP ? (threadIdx.x >> 6) * 64 : 0);
+    uint4* const                  wwin = s_win + (COOP ? (threadIdx.x >> 6) * 64 : 0);
+    volatile uint32_t* const      wown = s_own + (COOP ? (threadIdx.x >> 6) * 64 : 0);
     int      sp   = 0;   // stack height
     int      base = 0;   // entries [base, sp) are in LDS, [0, base) in scratch
     uint2    stk[RTX_STACK];
@@ -1032,11 +1070,15 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             if (doInner && nI) ws[1]++, ws[2] += nI;
             if (doLeaf && nL) ws[3]++, ws[4] += nL;
         }
-        if (doInner && state == ST_INNER) {
+        const bool ranInner = doInner && state == ST_INNER;
+        if (ranInner) {
             uint2    nd;
             uint4    qa = make_uint4(0, 0, 0, 0), qb = qa; // CULL: {w0, w1, L.x, L.y}, {L.z, R.x, R.y, R.z}: the children's boxes
             if (CULL) {
                 qa = S.nodes32[2ull * node], qb = S.nodes32[2ull * node + 1];
+                // both halves requested before anything waits for the first (else the compiler sinks the boxes' loads
+                // below the leaf test: two trips to the cache per step)
+                asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w), "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
                 nd = make_uint2(qa.x, qa.y);
             } else {
                 nd = S.nodes[node];
@@ -1051,8 +1093,10 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     leafEnd = idx + nd.x;
                     bestT   = RTX_INF;
                     best    = HIT_MISS;
-                    curRef  = S.leaf_ref[idx];
-                    if (nd.x > 1u) curRef2 = S.leaf_ref[idx + 1];
+                    if (!COOP) {
+                        curRef = S.leaf_ref[idx];
+                        if (nd.x > 1u) curRef2 = S.leaf_ref[idx + 1];
+                    }
                 } else {
                     pop = true; // empty leaf: no hit here
                 }
@@ -1104,7 +1148,70 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                     pop = true;
                 }
             }
-        } else if (doLeaf && state == ST_LEAF) {
+        }
+        if (COOP && doLeaf) {
+            // Cooperative LEAF (all 64 lanes, wave-uniform): the pending primitive tests of every lane that sits in
+            // a leaf are laid end to end and dealt out one per lane, whoever owns the ray.  CheckHitLeafNode
+            // (kdtree.c:480-498) tests every primitive of a leaf against the same tMax and keeps the strictly
+            // smaller t, first in the list on ties: the minimum over (t, position in the list), which is what the
+            // 64-bit ds_min below computes (t > 0, so its bit pattern orders like the number).
+            const bool     isL   = state == ST_LEAF;
+            const uint32_t cnt   = isL ? leafEnd - leafPos : 0u;
+            const uint32_t incl  = wave_scan_add(cnt), excl = incl - cnt;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            wown[lane] = 0u;
+            wkey[lane] = ~0ull;
+            if (cnt != 0u && excl < 64u) wown[excl] = excl << 6 | lane; // head of this owner's run of slots
+            const uint32_t pk    = wave_scan_max(wown[lane]);
+            const uint32_t owner = pk & 63u, k = lane - (pk >> 6);
+            const bool     valid = lane < total;
+            const f3       so = mk3(lane_read(o.x, owner), lane_read(o.y, owner), lane_read(o.z, owner));
+            const f3       sd = mk3(lane_read(d.x, owner), lane_read(d.y, owner), lane_read(d.z, owner));
+            const float    sT = lane_read(tMax, owner);
+            const uint32_t sP = lane_read(leafPos, owner);
+            bool               hitS = false;
+            unsigned long long keyS = 0;
+            uint32_t           refS = 0;
+            float              uS = 0.0f, vS = 0.0f;
+            if (valid) {
+                refS = S.leaf_ref[sP + k];
+                float tS;
+                if (refS & RTX_REF_SPHERE) {
+                    hitS = Sphere_HitAt(S.sph[refS & 0x7FFFFFFFu], so, sd, RT_EPSILON, sT, tS);
+                } else {
+                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * refS;
+                    float4        a  = tp[0];
+#if TRI_WAIT
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)::"memory");
+#endif
+                    const float4 b = tp[1];
+                    const float  c = *(const float*)(tp + 2);
+                    hitS = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c), so, sd, RT_EPSILON, sT, tS, uS, vS);
+                }
+                if (hitS) {
+                    keyS = (unsigned long long)__float_as_uint(tS) << 32 | lane;
+                    atomicMin(wkey + owner, keyS);
+                }
+            }
+            if (hitS && *(volatile unsigned long long*)(wkey + owner) == keyS) wwin[owner] = make_uint4(refS, __float_as_uint(uS), __float_as_uint(vS), 0u);
+            if (cnt != 0u && excl < 64u) {
+                const uint32_t used = cnt < 64u - excl ? cnt : 64u - excl;
+                if (COUNT) vis.prim += used;
+                const unsigned long long kk = *(volatile unsigned long long*)(wkey + lane);
+                if (kk != ~0ull) {
+                    const float tW = __uint_as_float((uint32_t)(kk >> 32));
+                    if (tW < bestT) { // strict: an earlier step's hit wins a tie (it is earlier in the list)
+                        const uint4 w = wwin[lane];
+                        bestT = tW, best = w.x, bu = __uint_as_float(w.y), bv = __uint_as_float(w.z);
+                    }
+                }
+                leafPos += used;
+                if (leafPos == leafEnd) {
+                    if (best != HIT_MISS) fin = true; // a leaf that reports a hit ends the walk
+                    else pop = true;
+                }
+            }
+        } else if (!COOP && doLeaf && state == ST_LEAF && !ranInner) {
             // Two primitives of the leaf per step (when two are left and both are triangles): the pair goes through
             // the packed test, one vector instruction for both (Triangle_HitAt2); results are taken in list order.
             const uint32_t r0 = curRef, r1 = curRef2;
@@ -1532,9 +1639,11 @@ static int trace_variant()
     static int v = -1;
     if (v < 0) {
         // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine,
-        // 3: 2 + subtree-box culling (default).  0..2 walk the tree literally.
+        // 3: 2 + subtree-box culling, 4: 3 + cooperative leaves (default), 5: 2 + cooperative leaves.
+        // 0..2 and 5 walk the tree literally.
         const char* e = getenv("RTX_TRACE_VARIANT");
-        v             = e ? atoi(e) : 3;
+        v             = e ? atoi(e) : 4;
+        if (v < 0 || v > 5) v = 4;
     }
     return v;
 }
@@ -1545,7 +1654,9 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
     // default: the culled walk where its boxes help, else the literal one; RTX_TRACE_VARIANT overrides
-    const int variant = literal ? std::min(trace_variant(), 2) : (trace_variant() == 3 && !getenv("RTX_TRACE_VARIANT") && !sc->cull_useful) ? 2 : trace_variant();
+    const int  tv      = trace_variant();
+    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
+    const int  variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
     if (variant == 0) {
         unsigned nb = blocks_for(n, 64);
         if (count) {
@@ -1562,15 +1673,18 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     static uint32_t tune = 0;
     if (tune == 0) { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes)
         unsigned    a = 16, b = 8, c = REFILL_MIN;
+        if (tv >= 4) a = 4; // cooperative leaves fill their 64 slots from few lanes
         const char* e = getenv("RTX_TRACE_TUNE");
         if (e) sscanf(e, "%u,%u,%u", &a, &b, &c);
         a = std::min(std::max(a, 1u), 64u), b = std::min(std::max(b, 1u), 64u), c = std::min(std::max(c, 1u), 64u);
         tune = a | b << 8 | c << 16;
     }
     PersistKernel kern    = variant == 1   ? (count ? k_trace_persist<true> : k_trace_persist<false>)
-                            : variant == 2 ? (count ? k_trace_flat<true, false> : k_trace_flat<false, false>)
-                                           : (count ? k_trace_flat<true, true> : k_trace_flat<false, true>);
-    const int     slot    = (count ? 1 : 0) + (variant >= 3 ? 2 : 0);
+                            : variant == 2 ? (count ? k_trace_flat<true, false, false> : k_trace_flat<false, false, false>)
+                            : variant == 3 ? (count ? k_trace_flat<true, true, false> : k_trace_flat<false, true, false>)
+                            : variant == 4 ? (count ? k_trace_flat<true, true, true> : k_trace_flat<false, true, true>)
+                                           : (count ? k_trace_flat<true, false, true> : k_trace_flat<false, false, true>);
+    const int     slot    = (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
     if (sc->persist_blocks[slot] == 0) {
         int per_cu = 0, cus = 0;
         HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));

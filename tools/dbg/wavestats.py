@@ -14,5 +14,5 @@ for depth in range(1, 6):
     w, v, n = ws - prev, vv - prevv, st["rays_at_depth"][-1]
     prev, prevv = ws, vv
     it = max(w[0], 1)
-    print("depth %d rays %d | steps/ray node %.1f prim %.1f | wave iterations %d, rays per iteration-wave %.2f | INNER runs %.2f/iter, %.1f lanes | LEAF runs %.2f/iter, %.1f lanes | POP %.2f/iter, %.1f lanes | FIN %.2f/iter"
-          % (depth - 1, n, (v[0] + v[1] + v[3]) / n, v[2] / n, w[0], n / it, w[1] / it, w[2] / max(w[1], 1), w[3] / it, w[4] / max(w[3], 1), w[5] / it, w[6] / max(w[5], 1), w[7] / it))
+    print("depth %d rays %d | steps/ray node %.1f prim %.1f | wave iterations %d, rays per iteration-wave %.2f | INNER runs %.2f/iter, %.1f lanes | LEAF runs %.2f/iter, %.1f lanes, %.1f tests | POP %.2f/iter, %.1f lanes | FIN %.2f/iter"
+          % (depth - 1, n, (v[0] + v[1] + v[3]) / n, v[2] / n, w[0], n / it, w[1] / it, w[2] / max(w[1], 1), w[3] / it, w[4] / max(w[3], 1), v[2] / max(w[3], 1), w[5] / it, w[6] / max(w[5], 1), w[7] / it))
