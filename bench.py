@@ -183,7 +183,7 @@ def main():
                                                "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world,
                                                "ray_binning": v[13] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace_flat<false,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
+                         "traffic": traffic, "kernel": "k_trace_flat<false,true,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
                          "alg_bytes_per_ray": bytes_frame / rays_frame},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -958,9 +958,11 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     __shared__ unsigned long long s_key[COOP ? 256 : 1];
     __shared__ uint4              s_win[COOP ? 256 : 1];
     __shared__ uint32_t           s_own[COOP ? 256 : 1];
-    unsigned long long* const     wkey = s_key + (COOP ? (threadIdx.x >> 6) * 64 : 0);
-    uint4* const                  wwin = s_win + (COOP ? (threadIdx.x >> 6) * 64 : 0);
-    volatile uint32_t* const      wown = s_own + (COOP ? (threadIdx.x >> 6) * 64 : 0);
+    const uint32_t wv = COOP ? (threadIdx.x >> 6) * 64 : 0; // this wave's 64 slots (plain LDS accesses in program order:
+#define WKEY(i) s_key[wv + (i)]                                // the wave's LDS instructions execute in order, LDS_ORDER
+#define WWIN(i) s_win[wv + (i)]                                // keeps the compiler from moving them)
+#define WOWN(i) s_own[wv + (i)]
+#define LDS_ORDER() asm volatile("" ::: "memory")
     int      sp   = 0;   // stack height
     int      base = 0;   // entries [base, sp) are in LDS, [0, base) in scratch
     uint2    stk[RTX_STACK];
@@ -1159,10 +1161,12 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
             const uint32_t cnt   = isL ? leafEnd - leafPos : 0u;
             const uint32_t incl  = wave_scan_add(cnt), excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            wown[lane] = 0u;
-            wkey[lane] = ~0ull;
-            if (cnt != 0u && excl < 64u) wown[excl] = excl << 6 | lane; // head of this owner's run of slots
-            const uint32_t pk    = wave_scan_max(wown[lane]);
+            WOWN(lane) = 0u;
+            WKEY(lane) = ~0ull;
+            LDS_ORDER();
+            if (cnt != 0u && excl < 64u) WOWN(excl) = excl << 6 | lane; // head of this owner's run of slots
+            LDS_ORDER();
+            const uint32_t pk    = wave_scan_max(WOWN(lane));
             const uint32_t owner = pk & 63u, k = lane - (pk >> 6);
             const bool     valid = lane < total;
             const f3       so = mk3(lane_read(o.x, owner), lane_read(o.y, owner), lane_read(o.z, owner));
@@ -1190,18 +1194,20 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
                 }
                 if (hitS) {
                     keyS = (unsigned long long)__float_as_uint(tS) << 32 | lane;
-                    atomicMin(wkey + owner, keyS);
+                    atomicMin(&WKEY(owner), keyS);
                 }
             }
-            if (hitS && *(volatile unsigned long long*)(wkey + owner) == keyS) wwin[owner] = make_uint4(refS, __float_as_uint(uS), __float_as_uint(vS), 0u);
+            LDS_ORDER();
+            if (hitS && WKEY(owner) == keyS) WWIN(owner) = make_uint4(refS, __float_as_uint(uS), __float_as_uint(vS), 0u);
+            LDS_ORDER();
             if (cnt != 0u && excl < 64u) {
                 const uint32_t used = cnt < 64u - excl ? cnt : 64u - excl;
                 if (COUNT) vis.prim += used;
-                const unsigned long long kk = *(volatile unsigned long long*)(wkey + lane);
+                const unsigned long long kk = WKEY(lane);
                 if (kk != ~0ull) {
                     const float tW = __uint_as_float((uint32_t)(kk >> 32));
                     if (tW < bestT) { // strict: an earlier step's hit wins a tie (it is earlier in the list)
-                        const uint4 w = wwin[lane];
+                        const uint4 w = WWIN(lane);
                         bestT = tW, best = w.x, bu = __uint_as_float(w.y), bv = __uint_as_float(w.z);
                     }
                 }
