@@ -120,6 +120,13 @@ typedef struct {
     uint64_t fnv1a_nodes, fnv1a_refs; /* FNV-1a 64 over the flattened node words / leaf refs */
 } KDTreeStats;
 void KDTree_Stats(const KDTree* tree, KDTreeStats* out);
+/* KDTree_New with the recursion (kdtree.c:244-383) done by an external builder of rtx_kd_build's signature
+ * (include/rtx.h: the device build of librt_hip.so); boxes, world box and depth bound are computed here
+ * as KDTree_New does (kdtree.c:385-408).  The tree is the same, word for word. */
+typedef int  (*KDExternalBuild)(int device, const float* box_min_max, uint64_t n, uint64_t max_depth, const float* world_min_max,
+                                rtx_kd_tree* out);
+typedef void (*KDExternalFree)(rtx_kd_tree* tree);
+KDTree* KDTree_New_External(Object* objs, size_t len, KDExternalBuild build, KDExternalFree release, int device, double* ms_device);
 
 /* ---- world/scene.h ---- */
 typedef struct Scene Scene;
@@ -127,6 +134,7 @@ Scene* Scene_New(Skybox* skybox);                  /* scene.c:24  */
 void   Scene_Delete(Scene* scene);                 /* scene.c:60  */
 bool   Scene_Add_Object(Scene* scene, Object* obj);/* scene.c:168 (copies *obj) */
 bool   Scene_Prepare(Scene* scene);                /* scene.c:145: bounded/unbounded split + KDTree_New */
+bool   Scene_Prepare_External(Scene* scene, KDExternalBuild build, KDExternalFree release, int device, double* ms_device);
 size_t Scene_Object_Count(const Scene* scene);
 const KDTree* Scene_KDTree(const Scene* scene);
 

@@ -255,6 +255,30 @@ int rtx_material_bounce(rtx_scene* scene, uint32_t mat_index, size_t n, const fl
 /* Skybox_ColorAt (src/world/skybox.c:66-134) for n directions. */
 int rtx_skybox_color(rtx_scene* scene, size_t n, const float* dir_xyz, float* rgb);
 
+/* ---- SAH kd-tree build on the device: replaces the recursion under KDTree_New
+ *      (src/rt/accelerators/kdtree.c:244-444: BuildNode / ComputeSplitSAH / BuildParentNode /
+ *      BuildLeafNode) for the boxes CreateKDBBs (:385-403) produced.  Level-synchronous on the device,
+ *      every f32 operation of the SAH search is the reference's, and the result is numbered in the
+ *      reference's order (parent, RIGHT subtree, LEFT subtree; right child = parent + 1), so the three
+ *      arrays are identical to the ones the host build of rt_host.h produces — same node words, same
+ *      leaf lists.  box_min_max: n x {min x y z, max x y z} (host); world_min_max: BoxBoundingAll
+ *      (:207-230) of them; max_depth: (size_t)(8.0 + 1.8*log2(n)) (:408).  The arrays in `out` are
+ *      malloc'ed by the library: release them with rtx_kd_free. ---- */
+typedef struct rtx_kd_tree {
+    uint32_t* node_w0;       /* split plane (f32 bits) of an inner node | length of a leaf's list     */
+    uint32_t* node_w1;       /* tag:2 (axis 0/1/2, 3 = leaf) | idx:30 (left child | first leaf_ref)    */
+    uint64_t  n_nodes;
+    uint32_t* leaf_ref;      /* indices into the n boxes                                               */
+    uint64_t  n_refs;
+    uint64_t  root_index;
+    uint64_t  depth_reached; /* deepest level that holds a node (root = 0)                            */
+    double    ms_device;     /* wall time of the device part (levels), for the record                 */
+    double    ms_total;      /* + upload, download and the final numbering pass on the host           */
+} rtx_kd_tree;
+int  rtx_kd_build(int device, const float* box_min_max, uint64_t n, uint64_t max_depth, const float* world_min_max,
+                  rtx_kd_tree* out);
+void rtx_kd_free(rtx_kd_tree* tree);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,7 +52,7 @@ def build_host(force=False):
 
 def build_hip(force=False, extra=()):
     out = os.path.join(LIB, "librt_hip.so")
-    srcs = [os.path.join(CSRC, "rt_hip.hip"), os.path.join(CSRC, "rtx_device.h"), os.path.join(INC, "rtx.h")]
+    srcs = [os.path.join(CSRC, "rt_hip.hip"), os.path.join(CSRC, "rtx_device.h"), os.path.join(CSRC, "kd_build.h"), os.path.join(INC, "rtx.h")]
     if force or _newer(out, srcs):
         os.makedirs(LIB, exist_ok=True)
         _run([HIPCC, *HIP_FLAGS, *extra, "-I" + INC, "-I" + CSRC, srcs[0], "-o", out])

@@ -715,18 +715,15 @@ static size_t BuildNode(KDBuild& b, const std::vector<uint32_t>& vect, BoundingB
     return parentIndex;
 }
 
-extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
+// what KDTree_New prepares before the recursion: depth bound, primitive boxes, world box (kdtree.c:405-435)
+static KDTree* KDTree_Inputs(Object* objs, size_t len, std::vector<BoundingBox>& boxes)
 {
-    if (!objs || len == 0) {
-        set_err("KDTree_New: no objects");
-        return NULL;
-    }
     KDTree* tree       = new KDTree();
     tree->failed       = false;
     tree->depthReached = 0;
     tree->maxDepth     = (size_t)(8.0 + 1.8 * log2((double)len));
 
-    std::vector<BoundingBox> boxes(len); // CreateKDBBs, kdtree.c:385-403
+    boxes.resize(len); // CreateKDBBs, kdtree.c:385-403
     for (size_t i = 0; i < len; i++) boxes[i] = Surface_BoundingBox(&objs[i].surface);
 
     BoundingBox world = boxes[0]; // BoxBoundingAll, kdtree.c:207-230
@@ -737,6 +734,50 @@ extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
         }
     }
     tree->worldBox = world;
+    return tree;
+}
+
+extern "C" KDTree* KDTree_New_External(Object* objs, size_t len, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
+{
+    if (!objs || len == 0 || !build || !release) {
+        set_err("KDTree_New_External: no objects or no builder");
+        return NULL;
+    }
+    std::vector<BoundingBox> boxes;
+    KDTree*                  tree = KDTree_Inputs(objs, len, boxes);
+    std::vector<float>       flat(6 * len);
+    for (size_t i = 0; i < len; i++) {
+        for (int a = 0; a < 3; a++) flat[6 * i + a] = elem(boxes[i].min, a), flat[6 * i + 3 + a] = elem(boxes[i].max, a);
+    }
+    float world[6];
+    for (int a = 0; a < 3; a++) world[a] = elem(tree->worldBox.min, a), world[3 + a] = elem(tree->worldBox.max, a);
+    rtx_kd_tree out;
+    memset(&out, 0, sizeof out);
+    const int rc = build(device, flat.data(), len, tree->maxDepth, world, &out);
+    if (rc != 0) { // no silent fall-back to the host recursion: the caller asked for the external builder
+        set_err("KDTree_New_External: the external builder failed with code %d", rc);
+        delete tree;
+        return NULL;
+    }
+    tree->w0.assign(out.node_w0, out.node_w0 + out.n_nodes);
+    tree->w1.assign(out.node_w1, out.node_w1 + out.n_nodes);
+    tree->refs.assign(out.leaf_ref, out.leaf_ref + out.n_refs);
+    tree->rootIndex    = out.root_index;
+    tree->depthReached = out.depth_reached;
+    if (ms_device) *ms_device = out.ms_device;
+    release(&out);
+    return tree;
+}
+
+extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
+{
+    if (!objs || len == 0) {
+        set_err("KDTree_New: no objects");
+        return NULL;
+    }
+    std::vector<BoundingBox> boxes;
+    KDTree*                  tree  = KDTree_Inputs(objs, len, boxes);
+    const BoundingBox        world = tree->worldBox;
 
     std::vector<uint32_t> all(len);
     for (size_t i = 0; i < len; i++) all[i] = (uint32_t)i;
@@ -828,6 +869,21 @@ extern "C" bool Scene_Prepare(Scene* scene) // scene.c:145-166
         if (!scene->kdTree) return false;
     } else {
         scene->kdTree = NULL;
+    }
+    return true;
+}
+
+extern "C" bool Scene_Prepare_External(Scene* scene, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
+{
+    scene->kdObjects.reserve(scene->objects.size());
+    for (size_t i = 0; i < scene->objects.size(); i++) {
+        (Surface_Bounded(&scene->objects[i].surface) ? scene->kdObjects : scene->unboundObjs).push_back(scene->objects[i]);
+    }
+    scene->kdTree = NULL;
+    if (ms_device) *ms_device = 0.0;
+    if (!scene->kdObjects.empty()) {
+        scene->kdTree = KDTree_New_External(scene->kdObjects.data(), scene->kdObjects.size(), build, release, device, ms_device);
+        if (!scene->kdTree) return false;
     }
     return true;
 }

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -2130,3 +2131,5 @@ extern "C" int rtx_skybox_color(rtx_scene* sc, size_t n, const float* dir_xyz, f
     HIPCHECK(hipMemcpy(rgb, bc.p, n * 12, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
+
+#include "kd_build.h"

@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .host import (LIB_DIR, rtx_camera, rtx_render_params, rtx_scene_desc, rtx_stats)
+from .host import (LIB_DIR, rtx_camera, rtx_kd_tree, rtx_render_params, rtx_scene_desc, rtx_stats)
 
 RTX_RENDER_COUNT_VISITS = 1
 RTX_RENDER_PIXEL_CENTRES = 2
@@ -19,7 +19,7 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free"]
 
 _lib = None
 
@@ -66,8 +66,28 @@ def lib() -> C.CDLL:
     sig("rtx_material_bounce", C.c_int, vp, C.c_uint32, C.c_size_t, f32p, f32p, f32p, f32p, u8p, u32p, f32p, f32p,
         f32p, f32p, u8p)
     sig("rtx_skybox_color", C.c_int, vp, C.c_size_t, f32p, f32p)
+    sig("rtx_kd_build", C.c_int, C.c_int, f32p, C.c_uint64, C.c_uint64, f32p, C.POINTER(rtx_kd_tree))
+    sig("rtx_kd_free", None, C.POINTER(rtx_kd_tree))
     _lib = L
     return L
+
+
+def last_error() -> str:
+    return lib().rtx_last_error().decode(errors="replace")
+
+
+def kd_build(box_min_max: np.ndarray, max_depth: int, device: int = 0) -> dict:
+    """rtx_kd_build on n x 6 f32 boxes (min xyz, max xyz): node words, leaf lists and the timings."""
+    b = np.ascontiguousarray(box_min_max, np.float32).reshape(-1, 6)
+    world = np.concatenate([b[:, :3].min(axis=0), b[:, 3:].max(axis=0)]).astype(np.float32)
+    t = rtx_kd_tree()
+    _check(lib().rtx_kd_build(device, _p(b, C.c_float), len(b), max_depth, _p(world, C.c_float), C.byref(t)))
+    try:
+        return {"w0": np.ctypeslib.as_array(t.node_w0, (t.n_nodes,)).copy(), "w1": np.ctypeslib.as_array(t.node_w1, (t.n_nodes,)).copy(),
+                "refs": np.ctypeslib.as_array(t.leaf_ref, (max(t.n_refs, 1),))[:t.n_refs].copy(), "root": int(t.root_index),
+                "depth_reached": int(t.depth_reached), "ms_device": t.ms_device, "ms_total": t.ms_total}
+    finally:
+        lib().rtx_kd_free(C.byref(t))
 
 
 def _check(rc):

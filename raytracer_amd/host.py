@@ -97,6 +97,12 @@ class KDTreeStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class rtx_kd_tree(C.Structure):
+    _fields_ = [("node_w0", C.POINTER(C.c_uint32)), ("node_w1", C.POINTER(C.c_uint32)), ("n_nodes", C.c_uint64),
+                ("leaf_ref", C.POINTER(C.c_uint32)), ("n_refs", C.c_uint64), ("root_index", C.c_uint64),
+                ("depth_reached", C.c_uint64), ("ms_device", C.c_double), ("ms_total", C.c_double)]
+
+
 class rtx_material(C.Structure):
     _fields_ = [("type", C.c_uint32), ("tex", C.c_int32), ("p", C.c_float * 14)]
 
@@ -215,6 +221,8 @@ def lib() -> C.CDLL:
     sig("Scene_Delete", None, vp)
     sig("Scene_Add_Object", C.c_bool, vp, C.POINTER(Object))
     sig("Scene_Prepare", C.c_bool, vp)
+    sig("Scene_Prepare_External", C.c_bool, vp, vp, vp, C.c_int, C.POINTER(C.c_double))
+    sig("KDTree_New_External", vp, C.POINTER(Object), C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_double))
     sig("Scene_Object_Count", C.c_size_t, vp)
     sig("Scene_KDTree", vp, vp)
     sig("Mesh_New", vp)

@@ -88,7 +88,9 @@ def write_recipe(name: str, lines=None) -> str:
 class BuiltScene:
     """A host Scene built from a recipe; keeps every ctypes object the C side points at alive."""
 
-    def __init__(self, lines, base_dir=None):
+    def __init__(self, lines, base_dir=None, kd_device=None):
+        """kd_device: None = the host SAH build (KDTree_New); an ordinal = the device build of librt_hip.so
+        (rtx_kd_build) through Scene_Prepare_External — the same tree, word for word."""
         L = host.lib()
         base = base_dir or assets.cache_dir()
         self.L = L
@@ -192,7 +194,19 @@ class BuiltScene:
                 L.Scene_Add_Object(self.scene, C.byref(o))
         if not self.camera:
             raise ValueError("recipe has no camera")
-        if not L.Scene_Prepare(self.scene):
+        self.kd_ms_device = None
+        if kd_device is None:
+            ok = L.Scene_Prepare(self.scene)
+        else:
+            from . import hip  # fails loudly when librt_hip.so is missing
+            H = hip.lib()
+            ms = C.c_double(0.0)
+            ok = L.Scene_Prepare_External(self.scene, C.cast(H.rtx_kd_build, C.c_void_p), C.cast(H.rtx_kd_free, C.c_void_p),
+                                          int(kd_device), C.byref(ms))
+            self.kd_ms_device = ms.value
+            if not ok:
+                raise RuntimeError("%s / %s" % (host.last_error(), hip.last_error()))
+        if not ok:
             raise RuntimeError(host.last_error())
 
     # -- flattening ---------------------------------------------------------------------------
@@ -233,6 +247,6 @@ class BuiltScene:
             self.camera = None
 
 
-def build(name_or_lines) -> BuiltScene:
+def build(name_or_lines, kd_device=None) -> BuiltScene:
     lines = recipe(name_or_lines) if isinstance(name_or_lines, str) else list(name_or_lines)
-    return BuiltScene(lines)
+    return BuiltScene(lines, kd_device=kd_device)
