@@ -4,8 +4,8 @@
 // scratch against the *behaviour* of the reference (file:line cited per function); arithmetic that
 // decides the shape of the tree is kept op-for-op in binary32 so that, built with
 // `-O2 -ffp-contract=off`, the node and leaf-reference streams are identical to the ones the
-// reference's KDTree_New produces (checked by tests/test_kdtree_build.py against dumps of the real
-// reference, tests/golden/kd_*.json).
+// reference's KDTree_New produces (checked by tests/test_host_build.py against dumps of the real
+// reference, tests/golden/kd.json).
 //
 // No ray is traced in this file.
 

@@ -20,7 +20,7 @@
 //
 // All f32 arithmetic is the reference's, operation by operation (-ffp-contract=off, IEEE division);
 // the counts are integers.  tests/test_kd_build_gpu.py: node words and leaf lists identical to the
-// host build's (which tests/test_kdtree_build.py pins to dumps of the reference's own trees).
+// host build's (which tests/test_host_build.py pins to dumps of the reference's own trees).
 
 #define KD_MIN_LEAF_LOAD 4u            // kdtree.c:15-37
 #define KD_NUM_BUCKETS 32
@@ -30,7 +30,6 @@
 #define KD_TRAVERSAL_COST (1.0f)
 #define KD_LEFT_NODE_RELATIVE_COST (1.0f + (1.0f - KD_RIGHT_NODE_RELATIVE_COST))
 #define KD_MAX_CAND (2 * KD_NUM_BUCKETS + 2) // cap of the candidate loop (rt_host.cpp's, never reached by sane boxes)
-#define KD_BLOCK 256
 
 struct KdNode { // a node of the level being built
     float    lo[3], hi[3];
@@ -54,6 +53,8 @@ DEV float kd_surface_area(const float lo[3], const float hi[3]) // kdtree.c:198-
     return 2 * x * y + 2 * x * z + 2 * y * z;
 }
 
+// KD_BLOCK: 256 threads per node on wide levels, 1024 on the narrow top levels, whose lists are long
+template <int KD_BLOCK>
 __global__ __launch_bounds__(KD_BLOCK) void k_kd_decide(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs,
                                                         const float* __restrict__ boxes, uint32_t depth_left,
                                                         KdDecision* __restrict__ out)
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(1024) void k_kd_scan(const KdDecision* __restrict__
     if (tid < 3) totals[tid] = s_run[tid];
 }
 
+template <int KD_BLOCK>
 __global__ __launch_bounds__(KD_BLOCK) void k_kd_emit(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs,
                                                       const float* __restrict__ boxes, const KdDecision* __restrict__ dec,
                                                       const uint32_t* __restrict__ off, uint32_t m, KdTopo* __restrict__ topo,
@@ -310,8 +312,9 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
         HIPCHECK(off.need(3 * m * 4, 0));
         HIPCHECK(topo.need((n_topo + m) * sizeof(KdTopo), n_topo * sizeof(KdTopo)));
         const uint32_t depth_left = (uint32_t)(max_depth > level ? max_depth - level : 0);
-        hipLaunchKernelGGL(k_kd_decide, dim3((unsigned)m), dim3(KD_BLOCK), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(),
-                           depth_left, dec.as<KdDecision>());
+        const bool narrow = m <= 4096; // few nodes, long lists: four times the threads per node
+        hipLaunchKernelGGL(narrow ? k_kd_decide<1024> : k_kd_decide<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
+                           refs[cur].as<uint32_t>(), boxes.as<float>(), depth_left, dec.as<KdDecision>());
         hipLaunchKernelGGL(k_kd_scan, dim3(1), dim3(1024), 0, 0, dec.as<KdDecision>(), (uint32_t)m, off.as<uint32_t>(), totals.as<uint64_t>());
         HIPCHECK(hipGetLastError());
         uint64_t tot[3];
@@ -321,7 +324,8 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
         HIPCHECK(nodes[cur ^ 1].need(std::max<uint64_t>(tot[0], 1) * sizeof(KdNode), 0));
         HIPCHECK(refs[cur ^ 1].need(std::max<uint64_t>(tot[1], 1) * 4, 0));
         HIPCHECK(pool.need(std::max<uint64_t>(n_pool + tot[2], 1) * 4, n_pool * 4));
-        hipLaunchKernelGGL(k_kd_emit, dim3((unsigned)m), dim3(KD_BLOCK), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(),
+        hipLaunchKernelGGL(narrow ? k_kd_emit<1024> : k_kd_emit<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
+                           refs[cur].as<uint32_t>(), boxes.as<float>(),
                            dec.as<KdDecision>(), off.as<uint32_t>(), (uint32_t)m, topo.as<KdTopo>(), (uint32_t)n_topo, (uint32_t)(n_topo + m),
                            pool.as<uint32_t>(), (uint32_t)n_pool, nodes[cur ^ 1].as<KdNode>(), refs[cur ^ 1].as<uint32_t>());
         HIPCHECK(hipGetLastError());
