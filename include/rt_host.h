@@ -188,6 +188,14 @@ bool       Render_Done(RenderCtx* ctx);                                         
  * the status of the last finished render (RTX_OK or RTX_E_*), and its stats. */
 void Render_Set_Seed(RenderCtx* ctx, uint64_t seed_lo, uint64_t seed_hi);
 void Render_Set_Device(RenderCtx* ctx, int device);
+/* Progressive frame for the next Render_Start (main.c:436-478 polls and blits ctx->img->pix every
+ * 200 ms while the workers fill it in): spp_per_pass > 0 makes the image fill in by passes of that many samples
+ * (rtx_render_progressive); a frame that runs to the end is byte-identical to the all-at-once frame.
+ * Render_Stop (main.c:47-58, the SIGINT export) ends it after the pass in flight: Render_Done turns true and
+ * ctx->img->pix holds the average of Render_Samples_Done samples. */
+void     Render_Set_Progressive(RenderCtx* ctx, uint32_t spp_per_pass);
+void     Render_Stop(RenderCtx* ctx);
+uint32_t Render_Samples_Done(RenderCtx* ctx);
 int  Render_Status(RenderCtx* ctx, rtx_stats* stats_or_null);
 
 const char* RtHost_LastError(void);

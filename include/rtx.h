@@ -180,6 +180,8 @@ typedef struct rtx_stats {
     /* COUNT_VISITS, rtx_render*: closest-hit wave statistics summed over waves — loop iterations, INNER block
      * runs and the lanes they served, LEAF runs and lanes, POP runs and lanes, FIN runs */
     uint64_t wave_stats[8];
+    uint32_t samples_done; /* rtx_render_progressive: samples per pixel in the image when the call returned */
+    uint32_t pad_;
 } rtx_stats;
 
 /* ---- library ---- */
@@ -221,8 +223,22 @@ int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, ui
 int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,
                uint8_t* bgr_out, float* accum_out, rtx_stats* stats);
 
+/* Progressive frame.  The reference's workers write finished tiles into ImageRGB.pix while the
+ * preview loop blits it every 200 ms (src/main.c:436-478) and a SIGINT dumps what is there (:47-58).  Here the
+ * frame fills in by SAMPLES: passes of `spp_per_pass` samples of every assigned pixel; after each pass bgr_out
+ * (host, may be read concurrently by a preview: every byte is always a valid pixel value) holds the image of
+ * the samples so far, sum * (1.0f/samples_done), and `progress` (may be NULL) is called — a nonzero return
+ * stops the frame there (the partial export), which is not an error.  The accumulation continues the
+ * sequential per-pixel sum in sample order across passes (renderer.c:98-107), so a frame that runs to the
+ * end is BYTE-IDENTICAL to rtx_render's, whatever spp_per_pass.  Blocking; accum_out as in rtx_render. */
+typedef int (*rtx_progress_fn)(void* user, uint32_t samples_done, uint32_t samples_total);
+int rtx_render_progressive(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, uint32_t spp_per_pass,
+                           uint8_t* bgr_out, float* accum_out, rtx_progress_fn progress, void* user, rtx_stats* stats);
+
 /* Device-output variant for multi-GPU: d_accum (f32 x 3 x W x H, device) receives the per-pixel
- * sums of the rows/samples assigned to this call and must be zero-filled by the caller beforehand;
+ * sums of the rows/samples assigned to this call, ADDED sample by sample, in sample order, to what the buffer
+ * holds (zero-fill it before the first call of a frame; a later call with the next sample range continues the
+ * same sequential sum);
  * the caller reduces it across ranks (RCCL) and then calls rtx_resolve_device. Runs on `stream`
  * and synchronises it before returning (stats need the event times). */
 int rtx_render_device(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params,

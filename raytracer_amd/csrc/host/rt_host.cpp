@@ -1266,6 +1266,7 @@ struct HipLib {
     int (*scene_create)(const rtx_scene_desc*, int, rtx_scene**);
     int (*scene_destroy)(rtx_scene*);
     int (*render)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint8_t*, float*, rtx_stats*);
+    int (*render_progressive)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint32_t, uint8_t*, float*, rtx_progress_fn, void*, rtx_stats*);
     const char* (*last_error)(void);
 };
 
@@ -1297,7 +1298,8 @@ static HipLib* load_hip_lib()
     lib.scene_destroy = (decltype(lib.scene_destroy))dlsym(h, "rtx_scene_destroy");
     lib.render        = (decltype(lib.render))dlsym(h, "rtx_render");
     lib.last_error    = (decltype(lib.last_error))dlsym(h, "rtx_last_error");
-    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.last_error) {
+    lib.render_progressive = (decltype(lib.render_progressive))dlsym(h, "rtx_render_progressive");
+    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.render_progressive || !lib.last_error) {
         set_err("Render_Start: %s lacks the rtx_* entry points", path.c_str());
         dlclose(h);
         return NULL;
@@ -1311,6 +1313,9 @@ struct WaiterArgs {
     size_t     samples_per_pixel, max_ray_depth;
     uint64_t   seed_lo, seed_hi;
     int        device;
+    uint32_t   spp_per_pass; // 0: the frame appears at once; else it fills in by passes of that many samples
+    volatile int stop;       // Render_Stop: end the frame after the pass in flight
+    volatile uint32_t samples_done;
     int        status;
     rtx_stats  stats;
     char       err[512];
@@ -1365,6 +1370,21 @@ extern "C" void Render_Set_Seed(RenderCtx* ctx, uint64_t lo, uint64_t hi)
 
 extern "C" void Render_Set_Device(RenderCtx* ctx, int device) { ((WaiterArgs*)ctx->waiter_args)->device = device; }
 
+// The reference's image fills in tile by tile while main.c blits it every 200 ms (main.c:436-478); here it
+// fills in by samples: after every pass of `spp_per_pass` samples ctx->img->pix holds the image so far.
+extern "C" void Render_Set_Progressive(RenderCtx* ctx, uint32_t spp_per_pass) { ((WaiterArgs*)ctx->waiter_args)->spp_per_pass = spp_per_pass; }
+// main.c:47-58 (SIGINT: stop and export what is there): ends a progressive frame after the pass in flight;
+// Render_Done then turns true with the partial image in ctx->img->pix.
+extern "C" void     Render_Stop(RenderCtx* ctx) { ((WaiterArgs*)ctx->waiter_args)->stop = 1; }
+extern "C" uint32_t Render_Samples_Done(RenderCtx* ctx) { return ((WaiterArgs*)ctx->waiter_args)->samples_done; }
+
+static int Render_Progress(void* user, uint32_t done, uint32_t)
+{
+    WaiterArgs* wa   = (WaiterArgs*)user;
+    wa->samples_done = done;
+    return wa->stop;
+}
+
 extern "C" int Render_Status(RenderCtx* ctx, rtx_stats* stats)
 {
     WaiterArgs* wa = (WaiterArgs*)ctx->waiter_args;
@@ -1407,7 +1427,12 @@ static void* Render_Waiter(void* arg) // stands in for Render_Waiter + Render_Wo
         p.seed_lo   = wa->seed_lo;
         p.seed_hi   = wa->seed_hi;
         static_assert(sizeof(RGB) == 3, "RGB is 3 bytes");
-        wa->status = lib->render(dev, (const rtx_camera*)ctx->cam, &p, (uint8_t*)ctx->img->pix, NULL, &wa->stats);
+        if (wa->spp_per_pass)
+            wa->status = lib->render_progressive(dev, (const rtx_camera*)ctx->cam, &p, wa->spp_per_pass, (uint8_t*)ctx->img->pix, NULL, Render_Progress,
+                                                 wa, &wa->stats);
+        else
+            wa->status = lib->render(dev, (const rtx_camera*)ctx->cam, &p, (uint8_t*)ctx->img->pix, NULL, &wa->stats);
+        wa->samples_done = wa->stats.samples_done;
         if (wa->status != RTX_OK) snprintf(wa->err, sizeof wa->err, "%s", lib->last_error());
     }
 done:
@@ -1422,6 +1447,8 @@ extern "C" void Render_Start(RenderCtx* ctx, size_t samples_per_pixel, size_t ma
     WaiterArgs* wa = (WaiterArgs*)ctx->waiter_args;
     join_waiter(wa);
     ctx->finished         = false;
+    wa->stop              = 0;
+    wa->samples_done      = 0;
     wa->samples_per_pixel = samples_per_pixel;
     wa->max_ray_depth     = max_ray_depth;
     if (pthread_create(&wa->thread, NULL, Render_Waiter, wa) != 0) {

@@ -1487,13 +1487,23 @@ __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint
 // through LDS (64-byte runs per pixel on the global side, stride-17 rows on the LDS side: conflict-free).
 #define RESOLVE_CH 16
 __global__ __launch_bounds__(256) void k_resolve_slab(const float* __restrict__ result, uint64_t rcap, FrameGeom g,
-                                                       uint64_t first_pixel, uint64_t n_pixels, float* __restrict__ accum)
+                                                       uint64_t first_pixel, uint64_t n_pixels, float* accum)
 {
     __shared__ float s_tile[256 * (RESOLVE_CH + 1)];
     const uint64_t p0 = (uint64_t)blockIdx.x * 256;
     const uint64_t p  = p0 + threadIdx.x;
     const uint32_t ns = g.n_samples;
-    float          cum[3] = {0.0f, 0.0f, 0.0f};
+    // the sum continues from what the frame buffer holds (zero before the frame's first sample range): a frame
+    // rendered in several sample ranges, in order, is the same sequential sum as a frame rendered at once
+    uint64_t o = 0;
+    float    cum[3] = {0.0f, 0.0f, 0.0f};
+    if (p < n_pixels) {
+        const uint64_t pl = first_pixel + slab_pixel(g, p);
+        const uint32_t xx = (uint32_t)(pl % g.width);
+        const uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+        o                 = ((uint64_t)yy * g.width + xx) * 3;
+        cum[0] = accum[o + 0], cum[1] = accum[o + 1], cum[2] = accum[o + 2];
+    }
     for (int c = 0; c < 3; c++) {
         for (uint32_t k = 0; k < ns; k += RESOLVE_CH) {
             const uint32_t len = min((uint32_t)RESOLVE_CH, ns - k);
@@ -1508,13 +1518,9 @@ __global__ __launch_bounds__(256) void k_resolve_slab(const float* __restrict__ 
         }
     }
     if (p >= n_pixels) return;
-    uint64_t pl = first_pixel + slab_pixel(g, p);
-    uint32_t xx = (uint32_t)(pl % g.width);
-    uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
-    uint64_t o  = ((uint64_t)yy * g.width + xx) * 3;
-    accum[o + 0] += cum[0];
-    accum[o + 1] += cum[1];
-    accum[o + 2] += cum[2];
+    accum[o + 0] = cum[0];
+    accum[o + 1] = cum[1];
+    accum[o + 2] = cum[2];
 }
 
 DEV uint8_t LinearTosRGB(float channel) // src/gfx/color.c:18-29
@@ -1978,6 +1984,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2], local.visits_culled = c[3];
     local.hits_shaded  = c[4];
     for (int i = 0; i < 8; i++) local.wave_stats[i] = c[8 + i];
+    local.samples_done = g.n_samples;
     if (stats) *stats = local;
     return RTX_OK;
 }
@@ -1992,27 +1999,53 @@ extern "C" int rtx_resolve_device(rtx_scene* sc, const float* d_accum, uint32_t 
     return RTX_OK;
 }
 
-extern "C" int rtx_render(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, uint8_t* bgr_out, float* accum_out, rtx_stats* stats)
+static void add_stats(rtx_stats& t, const rtx_stats& s)
+{
+    t.rays_total += s.rays_total, t.camera_paths += s.camera_paths, t.hits_shaded += s.hits_shaded;
+    t.visits_inner += s.visits_inner, t.visits_leaf += s.visits_leaf, t.visits_prim += s.visits_prim, t.visits_culled += s.visits_culled;
+    t.ms_total += s.ms_total, t.ms_trace += s.ms_trace, t.ms_shade += s.ms_shade, t.ms_raygen += s.ms_raygen, t.ms_resolve += s.ms_resolve;
+    t.ms_sort += s.ms_sort, t.trace_launches += s.trace_launches, t.passes += s.passes;
+    for (int i = 0; i < RTX_MAX_DEPTH; i++) t.rays_at_depth[i] += s.rays_at_depth[i], t.ms_trace_at_depth[i] += s.ms_trace_at_depth[i];
+    for (int i = 0; i < 8; i++) t.wave_stats[i] += s.wave_stats[i];
+}
+
+static int render_host(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, uint32_t spp_per_pass, uint8_t* bgr_out, float* accum_out,
+                       rtx_progress_fn progress, void* user, rtx_stats* stats)
 {
     if (!sc || !cam || !p) return fail(RTX_E_INVALID, "null argument");
+    FrameGeom g;
+    uint32_t  rows;
+    int       rc = check_params(p, &g, &rows);
+    if (rc != RTX_OK) return rc;
     HIPCHECK(hipSetDevice(sc->device));
     const uint64_t npx = (uint64_t)p->width * p->height;
     DevBuf         bacc, bbgr;
     HIPCHECK(bacc.alloc(npx * 12));
     HIPCHECK(bbgr.alloc(npx * 3));
     HIPCHECK(hipMemset(bacc.p, 0, npx * 12));
-    int rc = rtx_render_device(sc, cam, p, bacc.as<float>(), nullptr, stats);
-    if (rc != RTX_OK) return rc;
-    if (bgr_out) {
-        rc = rtx_resolve_device(sc, bacc.as<float>(), p->width, p->height, p->spp, bbgr.as<uint8_t>(), nullptr);
+    rtx_stats total;
+    memset(&total, 0, sizeof total);
+    const uint32_t sb = g.sample_begin, se = g.sample_begin + g.n_samples;
+    const uint32_t step = spp_per_pass ? spp_per_pass : g.n_samples; // 0: the whole range at once (rtx_render)
+    for (uint32_t s = sb; s < se; s += std::min(step, se - s)) {
+        rtx_render_params q = *p;
+        q.sample_begin = s, q.sample_end = s + std::min(step, se - s);
+        rtx_stats st;
+        rc = rtx_render_device(sc, cam, &q, bacc.as<float>(), nullptr, &st);
         if (rc != RTX_OK) return rc;
-        HIPCHECK(hipMemcpy(bgr_out, bbgr.p, npx * 3, hipMemcpyDeviceToHost));
+        add_stats(total, st);
+        total.samples_done = q.sample_end - sb;
+        if (bgr_out) { // the whole job's average once every sample is in (renderer.c:109), else the average so far
+            const uint32_t denom = q.sample_end == se ? p->spp : total.samples_done;
+            rc = rtx_resolve_device(sc, bacc.as<float>(), p->width, p->height, denom, bbgr.as<uint8_t>(), nullptr);
+            if (rc != RTX_OK) return rc;
+            HIPCHECK(hipMemcpy(bgr_out, bbgr.p, npx * 3, hipMemcpyDeviceToHost));
+        }
+        if (progress && progress(user, total.samples_done, se - sb) != 0) break;
     }
+    if (stats) *stats = total;
     if (accum_out) {
         // rows not assigned to this call stay untouched in the caller's buffer
-        FrameGeom g;
-        uint32_t  rows;
-        check_params(p, &g, &rows);
         if (g.band_rows == 0) {
             HIPCHECK(hipMemcpy(accum_out, bacc.p, npx * 12, hipMemcpyDeviceToHost));
         } else {
@@ -2024,6 +2057,18 @@ extern "C" int rtx_render(rtx_scene* sc, const rtx_camera* cam, const rtx_render
         }
     }
     return RTX_OK;
+}
+
+extern "C" int rtx_render(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, uint8_t* bgr_out, float* accum_out, rtx_stats* stats)
+{
+    return render_host(sc, cam, p, 0, bgr_out, accum_out, nullptr, nullptr, stats);
+}
+
+extern "C" int rtx_render_progressive(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, uint32_t spp_per_pass, uint8_t* bgr_out,
+                                      float* accum_out, rtx_progress_fn progress, void* user, rtx_stats* stats)
+{
+    if (spp_per_pass == 0) return fail(RTX_E_INVALID, "rtx_render_progressive: spp_per_pass must be positive");
+    return render_host(sc, cam, p, spp_per_pass, bgr_out, accum_out, progress, user, stats);
 }
 
 // ---------------------------------------------------------------------------------------------

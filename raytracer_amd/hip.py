@@ -18,7 +18,7 @@ RTX_ID_UNBOUNDED = 0x80000000
 
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
-           "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
+           "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
            "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free"]
 
 _lib = None
@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
     sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
     sig("rtx_render", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), u8p, f32p,
         C.POINTER(rtx_stats))
+    sig("rtx_render_progressive", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_uint32, u8p, f32p,
+        vp, vp, C.POINTER(rtx_stats))
     sig("rtx_render_device", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), vp, vp,
         C.POINTER(rtx_stats))
     sig("rtx_resolve_device", C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp)
@@ -199,6 +201,18 @@ class DeviceScene:
         st = rtx_stats()
         _check(lib().rtx_render(self.handle, C.byref(cam), C.byref(params), _p(bgr, C.c_uint8), _p(acc, C.c_float),
                                 C.byref(st)))
+        return bgr, acc, stats_dict(st)
+
+    def render_progressive(self, cam, params, spp_per_pass, on_pass=None, want_accum=True):
+        """rtx_render_progressive: on_pass(samples_done, samples_total, bgr) is called after every pass with the
+        image so far (a view of the output buffer); a true return value stops the frame there."""
+        bgr = np.zeros((params.height, params.width, 3), np.uint8)
+        acc = np.zeros((params.height, params.width, 3), np.float32) if want_accum else None
+        st = rtx_stats()
+        cb_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
+        cb = cb_t(lambda user, done, total: 1 if (on_pass and on_pass(done, total, bgr)) else 0)
+        _check(lib().rtx_render_progressive(self.handle, C.byref(cam), C.byref(params), spp_per_pass, _p(bgr, C.c_uint8),
+                                            _p(acc, C.c_float), C.cast(cb, C.c_void_p), None, C.byref(st)))
         return bgr, acc, stats_dict(st)
 
     def render_device(self, cam, params, d_accum_ptr, stream=0):

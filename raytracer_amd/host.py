@@ -147,6 +147,7 @@ class rtx_stats(C.Structure):
         ("ms_raygen", C.c_double), ("ms_resolve", C.c_double), ("trace_launches", C.c_uint32), ("passes", C.c_uint32),
         ("ms_trace_at_depth", C.c_double * RTX_MAX_DEPTH),
         ("visits_culled", C.c_uint64), ("ms_sort", C.c_double), ("wave_stats", C.c_uint64 * 8),
+        ("samples_done", C.c_uint32), ("pad_", C.c_uint32),
     ]
 
 
@@ -245,6 +246,9 @@ def lib() -> C.CDLL:
     sig("Render_Start", None, C.POINTER(RenderCtx), C.c_size_t, C.c_size_t)
     sig("Render_Done", C.c_bool, C.POINTER(RenderCtx))
     sig("Render_Set_Seed", None, C.POINTER(RenderCtx), C.c_uint64, C.c_uint64)
+    sig("Render_Set_Progressive", None, vp, C.c_uint32)
+    sig("Render_Stop", None, vp)
+    sig("Render_Samples_Done", C.c_uint32, vp)
     sig("Render_Set_Device", None, C.POINTER(RenderCtx), C.c_int)
     sig("Render_Status", C.c_int, C.POINTER(RenderCtx), C.POINTER(rtx_stats))
     _lib = L

@@ -67,3 +67,68 @@ def test_render_loop_matches_the_c_abi_and_the_reference(built_scenes, device_sc
     fin = np.isfinite(g["cum"]).all(axis=2)
     assert psnr(pix[fin], g["bgr"][fin]) >= 30.0
     assert started_in < 1.0  # asynchronous: Render_Start does not wait for the frame
+
+
+# ---- progressive frame: the image fills in while it renders, and can be stopped and exported ----
+from util import bits  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_progressive_frame_is_byte_identical_to_the_frame_rendered_at_once(built_scenes, device_scenes):
+    sc, ds = built_scenes("teapot"), device_scenes("teapot")
+    p = hip.make_params(96, 54, 8, 8, seed=(1, 2))
+    bgr, acc, st = ds.render(sc.rtx_camera(), p)
+    seen = []
+
+    def on_pass(done, total, img):
+        seen.append((done, total, img.copy()))
+
+    bgr2, acc2, st2 = ds.render_progressive(sc.rtx_camera(), p, 3, on_pass)
+    assert [(d, t) for d, t, _ in seen] == [(3, 8), (6, 8), (8, 8)]
+    assert np.array_equal(bgr, bgr2) and np.array_equal(bits(acc), bits(acc2))  # the sequential sum, continued
+    assert np.array_equal(seen[-1][2], bgr) and not np.array_equal(seen[0][2], bgr)
+    assert st2["samples_done"] == 8 and st2["rays_total"] == st["rays_total"] and st2["passes"] == 3
+    # the image after the first pass is the 3-sample image: same sum as the sample range [0, 3) rendered alone
+    _, acc3, _ = ds.render(sc.rtx_camera(), hip.make_params(96, 54, 8, 8, seed=(1, 2), sample_range=(0, 3)))
+    stopped = ds.render_progressive(sc.rtx_camera(), p, 3, lambda done, total, img: True)
+    assert stopped[2]["samples_done"] == 3 and np.array_equal(bits(stopped[1]), bits(acc3))
+    assert np.array_equal(stopped[0], seen[0][2])  # sum * (1/3): the preview of three samples
+
+
+@pytest.mark.gpu
+def test_render_loop_progressive_and_stop(built_scenes, device_scenes):
+    sc, L = built_scenes("teapot"), host.lib()
+    w, h, spp, depth = 96, 54, 8, 8
+    status, whole, _, _ = _render_through_host(sc, w, h, spp, depth)
+    assert status == 0
+
+    def run(spp, per_pass, stop_after_first_update):
+        img = host.ImageRGB()
+        assert L.ImageRGB_Load_Empty(C.byref(img), w, h)
+        C.memset(img.pix, 0, w * h * 3)
+        ctx = L.Render_New(sc.scene, C.byref(img), sc.camera)
+        L.Render_Set_Progressive(ctx, per_pass)
+        L.Render_Start(ctx, spp, depth)
+        t0, partial_seen = time.time(), False
+        while not L.Render_Done(ctx):
+            assert time.time() - t0 < 120.0
+            done = L.Render_Samples_Done(ctx)
+            if 0 < done < spp:
+                partial_seen = True
+                if stop_after_first_update:
+                    L.Render_Stop(ctx)
+            time.sleep(0.001)
+        status, done = L.Render_Status(ctx, None), L.Render_Samples_Done(ctx)
+        pix = np.ctypeslib.as_array(C.cast(img.pix, C.POINTER(C.c_uint8)), (h, w, 3)).copy()
+        L.Render_Delete(ctx)
+        L.ImageRGB_Unload(C.byref(img))
+        return status, done, pix, partial_seen
+
+    status, done, pix, _ = run(spp, 2, False)
+    assert status == 0 and done == spp and np.array_equal(pix, whole)
+    # the SIGINT export (main.c:47-58): stop a long frame once something is there; what is there is a whole image
+    status, done, pix, partial_seen = run(4096, 1, True)
+    assert status == 0 and partial_seen and 0 < done < 4096
+    # ... namely the frame of the first `done` samples, as the C ABI renders it when stopped at the same point
+    same = device_scenes("teapot").render_progressive(sc.rtx_camera(), hip.make_params(w, h, 4096, depth), 1, lambda d, t, img: d >= done)
+    assert same[2]["samples_done"] == done and np.array_equal(pix, same[0])
