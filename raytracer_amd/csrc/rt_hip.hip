@@ -26,6 +26,8 @@
 #include "rtx.h"
 #include "rtx_device.h"
 
+#define RTX_MAX_LANES 4 // slabs of a frame in flight at once (rtx_render_device)
+
 // ray binning between bounce passes (see k_bin_count): cells per axis = 2^BIN_CELL_BITS, times 8 direction octants
 #ifndef BIN_CELL_BITS
 #define BIN_CELL_BITS 5
@@ -77,13 +79,17 @@ struct rtx_scene {
     std::vector<void*> allocs;
     uint64_t           bytes;
     // per-scene scratch reused across calls
-    uint64_t* d_counters; // [0..3] visits (inner, leaf, prim, culled), [4] shaded hits, [6] queue count, [16..79] work counters of the persistent kernels
+    uint64_t* d_counters; // (second lane: + 80) [0..3] visits (inner, leaf, prim, culled), [4] shaded hits, [6] queue count, [16..79] work counters of the persistent kernels
     hipEvent_t ev[2 * 1024];
     int        n_ev;
     // render workspace (path queues, hit records, per-path results): grown on demand, kept between
     // frames so that a render loop does not pay hipMalloc/hipFree of gigabytes per frame
     void*    ws;
     uint64_t ws_bytes;
+    // second lane of rtx_render_device (two slabs in flight on two streams, see there)
+    hipStream_t         aux_stream[RTX_MAX_LANES - 1];
+    hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
+    unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
     unsigned persist_blocks[8]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)] (0 = not queried yet)
 };
@@ -123,6 +129,12 @@ extern "C" int rtx_scene_destroy(rtx_scene* sc)
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->ws) (void)hipFree(sc->ws);
     for (int i = 0; i < sc->n_ev; i++) (void)hipEventDestroy(sc->ev[i]);
+    for (int i = 0; i < RTX_MAX_LANES - 1; i++) {
+        if (sc->aux_stream[i]) (void)hipStreamDestroy(sc->aux_stream[i]);
+        if (sc->ev_join[i]) (void)hipEventDestroy(sc->ev_join[i]);
+    }
+    if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    if (sc->h_alive) (void)hipHostFree(sc->h_alive);
     delete sc;
     return RTX_OK;
 }
@@ -385,6 +397,8 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     sc->n_ev      = 0;
     sc->ws        = nullptr;
     sc->ws_bytes  = 0;
+    sc->ev_fork = nullptr, sc->h_alive = nullptr;
+    for (int i = 0; i < RTX_MAX_LANES - 1; i++) sc->aux_stream[i] = nullptr, sc->ev_join[i] = nullptr;
     memset(sc->persist_blocks, 0, sizeof sc->persist_blocks);
     memset(&sc->dev, 0, sizeof sc->dev);
     SceneDev& S = sc->dev;
@@ -504,7 +518,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     UP(upload(sc, d->tex_data, (size_t)d->tex_texels * 3, &S.tex_data));
     {
         const uint64_t* c = nullptr;
-        std::vector<uint64_t> zeros(16 + 64, 0);
+        std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64), 0); // [80 * l ..]: queue count and work counters of lane l
         UP(upload(sc, zeros.data(), zeros.size(), &c));
         sc->d_counters = (uint64_t*)c;
     }
@@ -878,6 +892,12 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
 // current primitive.
 // ---------------------------------------------------------------------------------------------
 enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2 };
+// One wave per block: the waves share nothing, and a block's LDS and wave slots come free the moment ITS wave
+// has finished its last ray — with 4-wave blocks the slowest of four decided, which kept the next kernel's
+// blocks (the other lane of rtx_render_device, or simply the shade pass) out of the CU during the tail.
+#ifndef TRACE_BLOCK
+#define TRACE_BLOCK 64
+#endif
 #ifndef LDS_SLOTS
 #define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave (16 slots: fewer blocks per CU, 14 % slower)
 #endif
@@ -929,7 +949,7 @@ DEV float lane_read(float v, uint32_t src) { return __uint_as_float((uint32_t)__
 DEV uint32_t lane_read(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
 
 template <bool COUNT, bool CULL, bool COOP>
-__global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
                                                     uint32_t chunk, uint64_t* counters, uint32_t tune)
 {
@@ -953,12 +973,12 @@ __global__ __launch_bounds__(256) void k_trace_flat(SceneDev S, const float* __r
     // entries, conflict-free); older entries spill one at a time to the per-lane scratch array and
     // come back one at a time.  With the whole stack in scratch the 6144 resident waves kept ~30 MB
     // of stack lines alive and evicted the kd-tree from the 8 x 4 MB L2s (rocprof: TCC hit rate 50 %).
-    __shared__ uint2 s_stk[4 * LDS_SLOTS * 64];
+    __shared__ uint2 s_stk[(TRACE_BLOCK / 64) * LDS_SLOTS * 64];
     uint2* const     lstk = s_stk + (threadIdx.x >> 6) * (LDS_SLOTS * 64) + lane;
     // COOP: per wave, 64 owner slots {closest key (t bits << 32 | slot), winner's {ref, u, v}} and the slot -> owner map
-    __shared__ unsigned long long s_key[COOP ? 256 : 1];
-    __shared__ uint4              s_win[COOP ? 256 : 1];
-    __shared__ uint32_t           s_own[COOP ? 256 : 1];
+    __shared__ unsigned long long s_key[COOP ? TRACE_BLOCK : 1];
+    __shared__ uint4              s_win[COOP ? TRACE_BLOCK : 1];
+    __shared__ uint32_t           s_own[COOP ? TRACE_BLOCK : 1];
     const uint32_t wv = COOP ? (threadIdx.x >> 6) * 64 : 0; // this wave's 64 slots (plain LDS accesses in program order:
 #define WKEY(i) s_key[wv + (i)]                                // the wave's LDS instructions execute in order, LDS_ORDER
 #define WWIN(i) s_win[wv + (i)]                                // keeps the compiler from moving them)
@@ -1662,7 +1682,7 @@ static int trace_variant()
 }
 
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
-                        bool count, uint64_t* d_counters, bool literal)
+                        bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr)
 {
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
@@ -1698,24 +1718,26 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
                             : variant == 4 ? (count ? k_trace_flat<true, true, true> : k_trace_flat<false, true, true>)
                                            : (count ? k_trace_flat<true, false, true> : k_trace_flat<false, false, true>);
     const int     slot    = (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
+    const int     bs      = variant == 1 ? 256 : TRACE_BLOCK;
     if (sc->persist_blocks[slot] == 0) {
         int per_cu = 0, cus = 0;
-        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
+        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, 0));
         HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
+        const int wpb = bs / 64; // RTX_TRACE_BLOCKS_PER_CU counts groups of 4 waves (one per SIMD), whatever the block size
         if (per_cu < 1) per_cu = 1;
-        if (per_cu > 8) per_cu = 8;
-        if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e))); // experiments
+        if (per_cu * wpb > 32) per_cu = 32 / wpb;
+        if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e) * 4 / wpb)); // experiments
         sc->persist_blocks[slot] = (unsigned)(per_cu * cus);
     }
-    unsigned long long* work = (unsigned long long*)&sc->d_counters[16]; // 8 part counters, 64 B apart
+    if (!work) work = (unsigned long long*)&sc->d_counters[16]; // 8 part counters, 64 B apart
     HIPCHECK(hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), st));
     const unsigned resident = sc->persist_blocks[slot];
-    const uint64_t waves    = (uint64_t)resident * 4;
+    const uint64_t waves    = (uint64_t)resident * (bs / 64);
     // chunk: about 8 grabs per wave on big queues, never below one wave's worth
     uint64_t chunk = n / (waves * 8);
     chunk          = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
-    unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + 255) / 256);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
+    unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
@@ -1863,25 +1885,29 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         if (stats) *stats = local;
         return RTX_OK;
     }
+    // Lanes.  A closest-hit launch ends with a tail: the queue is empty and the longest rays still walk (about a
+    // microsecond per node step with the chip nearly idle: 0.8-1.7 ms per launch whatever the queue's size).  On a
+    // whole 1080p / 64 spp frame that is 6 % of the time; on a rank's share of a frame split over 8 GPUs it is a third.
+    // Below ~100 M paths the assigned pixels are therefore cut into two halves that go through the bounce loop on two
+    // streams, a pass of one overlapping the tail of the other (RTX_OVERLAP=0/1 forces it off/on).  The halves are
+    // independent slabs, so the frame is the same, bit for bit.
+    const char* ov_env  = getenv("RTX_OVERLAP"); // read per call: the tests switch it
+    const int   overlap = ov_env ? atoi(ov_env) : -1;
+    int lanes = overlap >= 1 ? std::min(overlap + 1, RTX_MAX_LANES) : (overlap == -1 && total <= (100ull << 20)) ? 2 : 1;
+    if ((uint32_t)lanes > rows) lanes = (int)rows;
     // slab sizing: whole pixels, at most `budget` paths in flight
     uint64_t budget = p->max_paths_in_flight ? p->max_paths_in_flight : (160ull << 20); // whole 1080p/64spp frame: 133 M paths, 18.6 GB of 288
     if (budget > 0xFFFFFF00ull) budget = 0xFFFFFF00ull; // path ids are u32
-    uint64_t px_per_slab = std::max<uint64_t>(1, budget / g.n_samples);
-    px_per_slab          = std::min(px_per_slab, n_pixels);
+    uint64_t px_per_slab = std::max<uint64_t>(1, budget / lanes / g.n_samples);
+    px_per_slab          = std::min(px_per_slab, (uint64_t)((rows + lanes - 1) / lanes) * g.width); // whole rows when the frame is halved
     const uint64_t cap   = px_per_slab * g.n_samples;
     if (cap > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "spp too large for one slab");
 
-    const uint64_t qbytes = cap * Q_RECORD * 4;
-    char*          ws     = nullptr;
-    const uint64_t bin_bytes = (4ull << BIN_BITS);
-    if ((rc = workspace(sc, 2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes, &ws)) != RTX_OK) return rc;
-    float*    qb[2]    = {(float*)ws, (float*)(ws + qbytes)};
-    auto      soa      = [&](int b) { return Queue{qb[b], cap, 1}; };
-    auto      aos      = [&](int b) { return Queue{qb[b], 1, Q_RECORD}; };
-    Hits      hits     = {(uint32_t*)(ws + 2 * qbytes), cap};
-    float*    result   = (float*)(ws + 2 * qbytes + cap * 16);
-    uint32_t* bin_keys = (uint32_t*)(ws + 2 * qbytes + cap * 16 + cap * 12);
-    uint32_t* bin_cnt  = (uint32_t*)(ws + 2 * qbytes + cap * 16 + cap * 12 + cap * 4);
+    const uint64_t qbytes     = cap * Q_RECORD * 4;
+    const uint64_t bin_bytes  = (4ull << BIN_BITS);
+    const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes + 255) & ~255ull;
+    char*          ws         = nullptr;
+    if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
     static int sort_depth = -1; // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never)
     if (sort_depth < 0) {
         const char* e = getenv("RTX_SORT_DEPTH");
@@ -1892,8 +1918,14 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         const char* e = getenv("RTX_SORT_EVERY");
         sort_every    = e ? std::max(1, atoi(e)) : 1;
     }
+    if (!sc->h_alive) HIPCHECK(hipHostMalloc((void**)&sc->h_alive, RTX_MAX_LANES * sizeof(unsigned long long)));
+    if (lanes > 1 && !sc->ev_fork) HIPCHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+    for (int l = 1; l < lanes; l++) {
+        if (sc->aux_stream[l - 1]) continue;
+        HIPCHECK(hipStreamCreateWithFlags(&sc->aux_stream[l - 1], hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&sc->ev_join[l - 1], hipEventDisableTiming));
+    }
 
-    unsigned long long* d_cnt    = (unsigned long long*)&sc->d_counters[6];
     unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
     HIPCHECK(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint64_t), st));
 
@@ -1902,72 +1934,131 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     if ((rc = get_event(sc, nev++, &evA)) != RTX_OK) return rc;
     if ((rc = get_event(sc, nev++, &evB)) != RTX_OK) return rc;
     HIPCHECK(hipEventRecord(evA, st));
+    if (lanes > 1) { // the other streams start after what the caller queued on the first (the zeroed frame buffer)
+        HIPCHECK(hipEventRecord(sc->ev_fork, st));
+        for (int l = 1; l < lanes; l++) HIPCHECK(hipStreamWaitEvent(sc->aux_stream[l - 1], sc->ev_fork, 0));
+    }
     struct Span { int a, b, kind; uint32_t depth; };
     std::vector<Span> spans;
-    uint32_t cur_depth = 0;
-    auto timed = [&](int kind, auto&& launch) -> int {
+    auto timed = [&](int kind, uint32_t depth, hipStream_t s, auto&& launch) -> int {
         hipEvent_t a, b;
         int        ia = nev, ib = nev + 1, r;
         if ((r = get_event(sc, nev++, &a)) != RTX_OK) return r;
         if ((r = get_event(sc, nev++, &b)) != RTX_OK) return r;
-        HIPCHECK(hipEventRecord(a, st));
+        HIPCHECK(hipEventRecord(a, s));
         launch();
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipEventRecord(b, st));
-        spans.push_back({ia, ib, kind, cur_depth});
+        HIPCHECK(hipEventRecord(b, s));
+        spans.push_back({ia, ib, kind, depth});
         return RTX_OK;
     };
 
-    for (uint64_t px0 = 0; px0 < n_pixels; px0 += px_per_slab) {
-        const uint64_t npx = std::min(px_per_slab, n_pixels - px0);
-        uint64_t       n   = npx * g.n_samples;
-        local.passes++;
-        local.camera_paths += n;
-        HIPCHECK(hipMemsetAsync(result, 0, cap * 12, st));
-        FrameGeom gs = g; // tile-major path order when the slab is made of whole rows
-        if (px0 % g.width == 0 && npx % g.width == 0 && npx / g.width >= 2 * PATH_TILE) gs.tile = PATH_TILE, gs.slab_rows = (uint32_t)(npx / g.width);
-        rc = timed(0, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(n, 256)), dim3(256), 0, st, *cam, gs, px0, n, soa(0)); });
-        if (rc != RTX_OK) return rc;
-        int   cur = 0;       // buffer that holds the queue of this depth
-        Queue qin = soa(0);  // its layout: SoA out of raygen / shade, AoS out of the binning pass
-        for (uint32_t depth = 0; depth < p->max_depth && n > 0; depth++) {
-            local.rays_at_depth[depth] += n;
-            local.rays_total += n;
-            cur_depth = depth;
-            rc = timed(1, [&] { (void)launch_trace(sc, qin.base, qin.es == 1 ? cap : 0, n, hits.base, cap, st, count, sc->d_counters, literal); });
-            if (rc != RTX_OK) return rc;
-            local.trace_launches++;
-            HIPCHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-            const int  last = depth + 1 == p->max_depth;
-            const bool bin  = !last && sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && n >= 65536;
-            if (bin) HIPCHECK(hipMemsetAsync(bin_cnt, 0, bin_bytes, st));
-            rc = timed(2, [&] {
-                hipLaunchKernelGGL(k_shade, dim3(blocks_for(n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, st, sc->dev, qin, hits, n, soa(cur ^ 1), d_cnt, d_shaded,
-                                   result, cap, last, bin ? bin_cnt : nullptr, bin_keys);
-            });
-            if (rc != RTX_OK) return rc;
-            unsigned long long alive = 0;
-            if (!last) {
-                HIPCHECK(hipMemcpyAsync(&alive, d_cnt, sizeof alive, hipMemcpyDeviceToHost, st));
-                HIPCHECK(hipStreamSynchronize(st));
-            }
-            n   = alive;
-            cur ^= 1;
-            qin = soa(cur);
-            if (bin && n > 0) {
-                rc = timed(4, [&] {
-                    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, bin_cnt);
-                    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(n, 256)), dim3(256), 0, st, qin, n, bin_cnt, bin_keys, aos(cur ^ 1));
-                });
-                if (rc != RTX_OK) return rc;
-                cur ^= 1;
-                qin = aos(cur);
-            }
-        }
-        rc = timed(3, [&] {
-            hipLaunchKernelGGL(k_resolve_slab, dim3(blocks_for(npx, 256)), dim3(256), 0, st, result, cap, gs, px0, npx, d_accum);
+    struct Lane {
+        hipStream_t         s;
+        float*              qb[2];
+        Hits                hits;
+        float*              result;
+        uint32_t *          bin_keys, *bin_cnt;
+        unsigned long long *d_cnt, *work, *h_alive;
+        uint64_t            px0, npx, n;
+        FrameGeom           gs;
+        int                 cur;
+        Queue               qin;
+        uint32_t            depth;
+        bool                active, bin, last;
+    } L[RTX_MAX_LANES];
+    for (int l = 0; l < lanes; l++) {
+        char* w       = ws + l * lane_bytes;
+        L[l].s        = l == 0 ? st : sc->aux_stream[l - 1];
+        L[l].qb[0]    = (float*)w, L[l].qb[1] = (float*)(w + qbytes);
+        L[l].hits     = Hits{(uint32_t*)(w + 2 * qbytes), cap};
+        L[l].result   = (float*)(w + 2 * qbytes + cap * 16);
+        L[l].bin_keys = (uint32_t*)(w + 2 * qbytes + cap * 16 + cap * 12);
+        L[l].bin_cnt  = (uint32_t*)(w + 2 * qbytes + cap * 16 + cap * 12 + cap * 4);
+        L[l].d_cnt    = (unsigned long long*)&sc->d_counters[80 * l + 6];
+        L[l].work     = (unsigned long long*)&sc->d_counters[80 * l + 16];
+        L[l].h_alive  = sc->h_alive + l;
+        L[l].active   = false;
+    }
+    auto soa = [&](const Lane& a, int b) { return Queue{a.qb[b], cap, 1}; };
+    auto aos = [&](const Lane& a, int b) { return Queue{a.qb[b], 1, Q_RECORD}; };
+
+    // one bounce pass of a lane: closest hit, shade + compaction, and the survivors' count on its way to the host
+    auto enqueue_depth = [&](Lane& a) -> int {
+        const uint32_t depth = a.depth;
+        local.rays_at_depth[depth] += a.n;
+        local.rays_total += a.n;
+        int r = timed(1, depth, a.s, [&] {
+            (void)launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work);
         });
-        if (rc != RTX_OK) return rc;
+        if (r != RTX_OK) return r;
+        local.trace_launches++;
+        HIPCHECK(hipMemsetAsync(a.d_cnt, 0, sizeof(unsigned long long), a.s));
+        a.last = depth + 1 == p->max_depth;
+        a.bin  = !a.last && sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && a.n >= 65536;
+        if (a.bin) HIPCHECK(hipMemsetAsync(a.bin_cnt, 0, bin_bytes, a.s));
+        r = timed(2, depth, a.s, [&] {
+            hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, a.s, sc->dev, a.qin, a.hits, a.n, soa(a, a.cur ^ 1), a.d_cnt,
+                               d_shaded, a.result, cap, a.last ? 1 : 0, a.bin ? a.bin_cnt : nullptr, a.bin_keys);
+        });
+        if (r != RTX_OK) return r;
+        *a.h_alive = 0;
+        if (!a.last) HIPCHECK(hipMemcpyAsync(a.h_alive, a.d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, a.s));
+        return RTX_OK;
+    };
+    uint64_t next_px = 0;
+    auto start_slab = [&](Lane& a) -> int { // the lane's next slab: camera rays, then its first pass
+        a.active = next_px < n_pixels;
+        if (!a.active) return RTX_OK;
+        a.px0 = next_px, a.npx = std::min(px_per_slab, n_pixels - next_px), a.n = a.npx * g.n_samples;
+        next_px += a.npx;
+        local.passes++;
+        local.camera_paths += a.n;
+        HIPCHECK(hipMemsetAsync(a.result, 0, cap * 12, a.s));
+        a.gs = g; // tile-major path order when the slab is made of whole rows
+        if (a.px0 % g.width == 0 && a.npx % g.width == 0 && a.npx / g.width >= 2 * PATH_TILE) a.gs.tile = PATH_TILE, a.gs.slab_rows = (uint32_t)(a.npx / g.width);
+        a.cur = 0, a.qin = soa(a, 0), a.depth = 0; // SoA out of raygen / shade, AoS out of the binning pass
+        int r = timed(0, 0, a.s, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, *cam, a.gs, a.px0, a.n, soa(a, 0)); });
+        return r != RTX_OK ? r : enqueue_depth(a);
+    };
+    auto advance = [&](Lane& a) -> int { // the lane's pass has finished: bin and go one deeper, or close the slab
+        a.n   = a.last ? 0 : *a.h_alive;
+        a.cur ^= 1;
+        a.qin = soa(a, a.cur);
+        if (a.bin && a.n > 0) {
+            int r = timed(4, a.depth, a.s, [&] {
+                hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, a.s, a.bin_cnt);
+                hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, a.qin, a.n, a.bin_cnt, a.bin_keys, aos(a, a.cur ^ 1));
+            });
+            if (r != RTX_OK) return r;
+            a.cur ^= 1;
+            a.qin = aos(a, a.cur);
+        }
+        a.depth++;
+        if (a.depth < p->max_depth && a.n > 0) return enqueue_depth(a);
+        int r = timed(3, 0, a.s, [&] {
+            hipLaunchKernelGGL(k_resolve_slab, dim3(blocks_for(a.npx, 256)), dim3(256), 0, a.s, a.result, cap, a.gs, a.px0, a.npx, d_accum);
+        });
+        return r != RTX_OK ? r : start_slab(a);
+    };
+    for (int l = 0; l < lanes; l++)
+        if ((rc = start_slab(L[l])) != RTX_OK) return rc;
+    // round robin: while the host waits for one lane's pass, the other lane's next pass is already queued
+    auto any_active = [&] {
+        for (int l = 0; l < lanes; l++)
+            if (L[l].active) return true;
+        return false;
+    };
+    while (any_active()) {
+        for (int l = 0; l < lanes; l++) {
+            if (!L[l].active) continue;
+            HIPCHECK(hipStreamSynchronize(L[l].s));
+            if ((rc = advance(L[l])) != RTX_OK) return rc;
+        }
+    }
+    for (int l = 1; l < lanes; l++) {
+        HIPCHECK(hipEventRecord(sc->ev_join[l - 1], sc->aux_stream[l - 1]));
+        HIPCHECK(hipStreamWaitEvent(st, sc->ev_join[l - 1], 0));
     }
     HIPCHECK(hipEventRecord(evB, st));
     HIPCHECK(hipStreamSynchronize(st));

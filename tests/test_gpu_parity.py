@@ -275,3 +275,22 @@ def test_full_size_frame_properties(built_scenes, device_scenes):
     assert same_bits(acc, a) and rays.tolist() == sa["rays_at_depth"]
     fin = np.isfinite(a).all(axis=2)
     assert fin.mean() > 0.999 and a[fin].min() >= 0.0
+
+
+@pytest.mark.gpu
+def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, monkeypatch):
+    """rtx_render_device cuts small jobs into two halves that run on two streams (a pass of one hides the tail of
+    the other).  The halves are independent slabs: same frame bit for bit, same ray counts, with either setting
+    and also when the halves are cut further into slabs."""
+    sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
+    p = hip.make_params(192, 108, 8, 8, seed=(1, 2))
+    frames = []
+    for ov, mpf in (("0", 0), ("1", 0), ("1", 20000), ("0", 20000)):
+        monkeypatch.setenv("RTX_OVERLAP", ov)
+        p.max_paths_in_flight = mpf
+        bgr, acc, st = ds.render(sc.rtx_camera(), p)
+        frames.append((bgr, acc, st))
+    for bgr, acc, st in frames[1:]:
+        assert np.array_equal(bgr, frames[0][0]) and same_bits(acc, frames[0][1])
+        assert st["rays_at_depth"] == frames[0][2]["rays_at_depth"]
+    assert frames[0][2]["passes"] == 1 and frames[1][2]["passes"] == 2 and frames[2][2]["passes"] > 4
