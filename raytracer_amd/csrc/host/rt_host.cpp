@@ -933,6 +933,78 @@ extern "C" void Mesh_AddToScene(Mesh* mesh, Scene* scene) // mesh.c:67-84
     }
 }
 
+// Fast paths of the importer.  The reference parses every line with up to three sscanf calls and every face
+// corner with up to four (mesh.c:104-153); on a 1.1 M-triangle file that is most of the scene build once the
+// kd-tree is built on the device.  A line or token of the plain shape every exporter writes ("v x y z" with
+// plain decimal numbers, "a/b/c" with plain digits) is parsed directly — strtof is what sscanf's %f calls, so
+// the floats are the same bits —; anything else (signs, hex floats, inf/nan, trailing text, odd spacing) takes
+// the sscanf path unchanged, so the quirks stay the reference's.
+static bool plain_number_at(const char* p)
+{
+    if (*p == '-') p++;
+    return (*p >= '0' && *p <= '9') || (*p == '.' && p[1] >= '0' && p[1] <= '9');
+}
+static bool is_blank(char c) { return c == ' ' || c == '\t'; }
+static bool fast_floats(const char* p, int n, float* out) // p just past the keyword; n plain numbers, blank-separated
+{
+    for (int i = 0; i < n; i++) {
+        if (!is_blank(*p)) return false;
+        while (is_blank(*p)) p++;
+        if (!plain_number_at(p)) return false;
+        const char* q = p;
+        if (*q == '-') q++;
+        while ((*q >= '0' && *q <= '9') || *q == '.') q++;
+        if (*q == 'e' || *q == 'E') {
+            const char* r = q + 1;
+            if (*r == '-' || *r == '+') r++;
+            if (!(*r >= '0' && *r <= '9')) return false;
+            while (*r >= '0' && *r <= '9') r++;
+            q = r;
+        }
+        // the number must end where the next blank / the line end begins: "1.0abc" or "0x10" go to sscanf
+        if (!(is_blank(*q) || *q == '\n' || *q == '\r' || *q == 0)) return false;
+        char* end = NULL;
+        out[i]    = strtof(p, &end);
+        if (end != q) return false;
+        p = q;
+    }
+    return true;
+}
+static bool fast_corner(const char* t, ssize_t* vi, ssize_t* vt, ssize_t* vn) // "a", "a/b", "a//c", "a/b/c", plain digits
+{
+    size_t f[3]   = {0, 0, 0};
+    bool   has[3] = {false, false, false};
+    int    k      = 0;
+    for (;;) {
+        int digits = 0;
+        while (*t >= '0' && *t <= '9') {
+            if (++digits > 18) return false;
+            f[k] = f[k] * 10 + (size_t)(*t - '0');
+            t++;
+        }
+        has[k] = digits > 0;
+        if (*t == '/' && k < 2) {
+            k++;
+            t++;
+            continue;
+        }
+        break;
+    }
+    if (!(*t == 0 || *t == '\n')) return false; // "\r", spaces, letters: sscanf decides
+    if (!has[0]) return false;
+    if (k == 0) {
+        *vi = (ssize_t)f[0];
+    } else if (k == 1) {
+        if (!has[1]) return false;
+        *vi = (ssize_t)f[0], *vt = (ssize_t)f[1];
+    } else {
+        if (!has[2]) return false; // "a/b/" and "a//": sscanf decides
+        *vi = (ssize_t)f[0], *vn = (ssize_t)f[2];
+        if (has[1]) *vt = (ssize_t)f[1];
+    }
+    return true;
+}
+
 extern "C" bool Mesh_Import_OBJ(Mesh* mesh, FILE* fd) // mesh.c:87-244
 {
     char                lineBuffer[512];
@@ -947,7 +1019,16 @@ extern "C" bool Mesh_Import_OBJ(Mesh* mesh, FILE* fd) // mesh.c:87-244
         point3 vn, v;
         point2 vt;
         if (!fgets(lineBuffer, sizeof lineBuffer, fd)) { /* buffer unchanged, like the reference */ }
-        if (sscanf(lineBuffer, "v %f %f %f\n", &v.x, &v.y, &v.z) == 3) {
+        float fv[3];
+        if (lineBuffer[0] == 'v' && is_blank(lineBuffer[1]) && fast_floats(lineBuffer + 1, 3, fv)) {
+            vertices.push_back(point3{fv[0], fv[1], fv[2]});
+        } else if (lineBuffer[0] == 'v' && lineBuffer[1] == 'n' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 3, fv)) {
+            vertexNormals.push_back(point3{fv[0], fv[1], fv[2]});
+        } else if (lineBuffer[0] == 'v' && lineBuffer[1] == 't' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 2, fv)) {
+            texCoords.push_back(point2{fv[0], fv[1]});
+        } else if (lineBuffer[0] != 'v') {
+            // none of the three patterns can match a line that does not start with 'v'
+        } else if (sscanf(lineBuffer, "v %f %f %f\n", &v.x, &v.y, &v.z) == 3) {
             vertices.push_back(v);
         } else if (sscanf(lineBuffer, "vt %f %f\n", &vt.x, &vt.y) == 2) {
             texCoords.push_back(vt);
@@ -972,7 +1053,8 @@ extern "C" bool Mesh_Import_OBJ(Mesh* mesh, FILE* fd) // mesh.c:87-244
                 set_err("Mesh_Import_OBJ: face with more than 4 vertices (the reference overruns vi[4], mesh.c:136)");
                 return false;
             }
-            if (sscanf(token, "%zu/%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc], (size_t*)&vn[tc]) == 3) {
+            if (fast_corner(token, &vi[tc], &vt[tc], &vn[tc])) {
+            } else if (sscanf(token, "%zu/%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc], (size_t*)&vn[tc]) == 3) {
             } else if (sscanf(token, "%zu//%zu", (size_t*)&vi[tc], (size_t*)&vn[tc]) == 2) {
             } else if (sscanf(token, "%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc]) == 2) {
             } else if (sscanf(token, "%zu", (size_t*)&vi[tc]) == 1) {

@@ -82,6 +82,52 @@ def test_obj_import_quads_tris_and_default_normals(tmp_path):
     L.Mesh_Delete(m)
 
 
+def test_obj_import_fast_and_sscanf_paths_agree(tmp_path):
+    """The importer parses plain lines directly and leaves everything else to the reference's sscanf chain
+    (mesh.c:104-153).  The same mesh written plainly and written with signs, hex floats, trailing text and
+    trailing blanks — which only sscanf accepts — must import to the same bits."""
+    L = host.lib()
+    rng = np.random.default_rng(5)
+    v = (rng.normal(size=(60, 3)) * 10.0 ** rng.integers(-6, 6, (60, 1))).astype(np.float32)
+    vt, vn = rng.random((40, 2)).astype(np.float32), rng.normal(size=(30, 3)).astype(np.float32)
+    faces = [(rng.integers(1, 61, 4), rng.integers(1, 41, 4), rng.integers(1, 31, 4), int(rng.integers(0, 4)), int(rng.integers(3, 5)))
+             for _ in range(80)]
+    r = lambda x: "%.9g" % x  # noqa: E731  (round-trips f32)
+
+    def odd(x, k):  # the same value in a spelling the fast path declines
+        x = float(x)
+        return [("+" + r(x)) if x >= 0 else "%.12e" % x, float.hex(x), "%+.12e" % x][k % 3]
+
+    def corner(a, b, c, kind, sign):
+        return [f"{sign}{a}/{sign}{b}/{sign}{c}", f"{sign}{a}//{sign}{c}", f"{sign}{a}/{sign}{b}", f"{sign}{a}"][kind]
+
+    plain = "".join("v %s %s %s\n" % tuple(map(r, x)) for x in v) + "".join("vt %s %s\n" % tuple(map(r, x)) for x in vt) + \
+        "".join("vn %s %s %s\n" % tuple(map(r, x)) for x in vn)
+    fancy = "".join("v %s  %s\t%s trailing\n" % (odd(x[0], i), odd(x[1], i + 1), odd(x[2], i + 2)) for i, x in enumerate(v)) + \
+        "".join("vt %s %s\n" % (odd(x[0], i), odd(x[1], i + 3)) for i, x in enumerate(vt)) + \
+        "".join("vn   %s %s %s\n" % (odd(x[0], i + 1), odd(x[1], i), odd(x[2], i + 2)) for i, x in enumerate(vn))
+    for a, b, c, kind, n in faces:
+        plain += "f " + " ".join(corner(a[k], b[k], c[k], kind, "") for k in range(n)) + "\n"
+        fancy += "f " + " ".join(corner(a[k], b[k], c[k], kind, "+") + ("x" if k == 1 else "") for k in range(n)) + "\n"
+    out = []
+    for i, text in enumerate((plain, fancy)):
+        pth = tmp_path / ("m%d.obj" % i)
+        pth.write_text(text)
+        m = L.Mesh_New()
+        assert L.Mesh_Import_OBJ_Path(m, str(pth).encode()), host.last_error()
+        n = L.Mesh_Triangle_Count(m)
+        out.append(np.ctypeslib.as_array(C.cast(L.Mesh_Triangles(m), C.POINTER(C.c_uint32)), (n, 24)).copy())
+        L.Mesh_Delete(m)
+    assert len(out[0]) == sum(2 if f[4] == 4 else 1 for f in faces) and np.array_equal(out[0], out[1])
+    # and the plain spelling really is what Python reads from the same text
+    m = L.Mesh_New()
+    (tmp_path / "one.obj").write_text("v 1.25 -2.5e-3 .5\nv 1 0 0\nv 0 1. 0\nf 1 2 3\n")
+    assert L.Mesh_Import_OBJ_Path(m, str(tmp_path / "one.obj").encode())
+    t = L.Mesh_Triangles(m)
+    assert (t[0].vtx[0].pos.x, t[0].vtx[0].pos.y, t[0].vtx[0].pos.z) == (1.25, float(np.float32(-2.5e-3)), 0.5)
+    L.Mesh_Delete(m)
+
+
 def test_obj_import_quad_default_normal_is_not_normalised(tmp_path):
     L = host.lib()
     m = L.Mesh_New()
