@@ -963,6 +963,52 @@ static bool fast_floats(const char* p, int n, float* out) // p just past the key
         }
         // the number must end where the next blank / the line end begins: "1.0abc" or "0x10" go to sscanf
         if (!(is_blank(*q) || *q == '\n' || *q == '\r' || *q == 0)) return false;
+        // Clinger's fast path: up to 15 significant digits and |exponent| <= 22 make mantissa and power of ten
+        // exact doubles, their product or quotient a correctly rounded double; rounding that to float is the
+        // correctly rounded float — what strtof returns — unless the double sits within an ulp of the midpoint
+        // of two floats (or outside the normal float range): those, and longer numbers, go to strtof itself.
+        {
+            const char* c = p;
+            bool        neg = false;
+            if (*c == '-') neg = true, c++;
+            uint64_t m = 0;
+            int      nd = 0, e10 = 0;
+            bool     ok = true, dot = false, lead = true;
+            for (; (*c >= '0' && *c <= '9') || *c == '.'; c++) {
+                if (*c == '.') {
+                    if (dot) { ok = false; break; }
+                    dot = true;
+                    continue;
+                }
+                if (lead && *c == '0') { if (dot) e10--; continue; }
+                lead = false;
+                if (++nd > 15) { ok = false; break; }
+                m = m * 10 + (uint64_t)(*c - '0');
+                if (dot) e10--;
+            }
+            if (ok && (*c == 'e' || *c == 'E')) {
+                c++;
+                bool eneg = false;
+                if (*c == '-') eneg = true, c++;
+                else if (*c == '+') c++;
+                int ev = 0, ed = 0;
+                for (; *c >= '0' && *c <= '9'; c++) { if (++ed > 4) { ok = false; break; } ev = ev * 10 + (*c - '0'); }
+                e10 += eneg ? -ev : ev;
+            }
+            static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+            if (ok && c == q && e10 >= -22 && e10 <= 22) {
+                const double d = e10 < 0 ? (double)m / P10[-e10] : (double)m * P10[e10];
+                uint64_t bits;
+                memcpy(&bits, &d, 8);
+                const uint64_t frac = bits & 0x1FFFFFFFull;
+                const bool     safe = m == 0 || ((d > 1.0e-30 && d < 1.0e30) && (frac < 0x0FFFFFFFull || frac > 0x10000001ull));
+                if (safe) {
+                    out[i] = neg ? -(float)d : (float)d;
+                    p      = q;
+                    continue;
+                }
+            }
+        }
         char* end = NULL;
         out[i]    = strtof(p, &end);
         if (end != q) return false;

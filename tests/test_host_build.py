@@ -128,6 +128,37 @@ def test_obj_import_fast_and_sscanf_paths_agree(tmp_path):
     L.Mesh_Delete(m)
 
 
+def test_obj_import_fast_float_path_is_strtof(tmp_path):
+    """Numbers of up to 15 digits are converted without strtof (exact double arithmetic, then one rounding to
+    f32 that is checked for the double-rounding case).  Same decimal text through sscanf — forced by a '+' on
+    the line's first number — must give the same bits, over magnitudes, digit counts and spellings."""
+    L = host.lib()
+    rng = np.random.default_rng(11)
+    n = 6000
+    x = rng.normal(size=(n, 2)) * 10.0 ** rng.integers(-32, 32, (n, 2))
+    fmts = ["%.9g", "%.17g", "%.15g", "%.6f", "%.3e", "%.12f", "%.1f"]
+    txt = [[fmts[(i + j) % len(fmts)] % x[i, j] for j in range(2)] for i in range(n)]
+    # midpoints of adjacent floats, written exactly (the double-rounding trap) and one digit short
+    f = np.abs(rng.normal(size=400)).astype(np.float32) + np.float32(0.5)
+    mid = (f.astype(np.float64) + np.nextafter(f, np.float32(np.inf)).astype(np.float64)) / 2
+    txt += [["%.17g" % m, "%.15g" % m] for m in mid]
+    plain = "".join("v 1.0 %s %s\n" % (a, b) for a, b in txt) + "f 1 2 3\n"
+    forced = "".join("v +1.0 %s %s\n" % (a, b) for a, b in txt) + "f 1 2 3\n"
+    got = []
+    for i, text in enumerate((plain, forced)):
+        # read the vertices back through n-2 fan triangles? simpler: one triangle per vertex triple
+        faces = "".join("f %d %d %d\n" % (k + 1, k + 2, k + 3) for k in range(0, len(txt) - 2, 3))
+        pth = tmp_path / ("n%d.obj" % i)
+        pth.write_text(text.replace("f 1 2 3\n", faces))
+        m = L.Mesh_New()
+        assert L.Mesh_Import_OBJ_Path(m, str(pth).encode()), host.last_error()
+        k = L.Mesh_Triangle_Count(m)
+        a = np.ctypeslib.as_array(C.cast(L.Mesh_Triangles(m), C.POINTER(C.c_uint32)), (k, 3, 8)).copy()
+        got.append(a[:, :, :3])  # positions only (default normals of huge triangles overflow alike, but keep it simple)
+        L.Mesh_Delete(m)
+    assert got[0].shape[0] == len(range(0, len(txt) - 2, 3)) and np.array_equal(got[0], got[1])
+
+
 def test_obj_import_quad_default_normal_is_not_normalised(tmp_path):
     L = host.lib()
     m = L.Mesh_New()
