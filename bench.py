@@ -31,11 +31,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
 def alg_bytes(vi, vl, vp, vc, rays):
-    """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d), for the walk the kernel actually does
-    (subtree-box culling on): an inner node it visits is the 8-B kd node + the two 12-B boxes of its children
-    = 32 B, a leaf it visits 8 B (children whose box the ray misses are never fetched: vc only counts them);
-    (4 B leaf ref + 36 B vertex positions) per primitive test; 64 B ray record read + 44 B hit record write
-    per ray.  The N_* are the kernel's own counters."""
+    """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d)'s per-unit figure: 8 B per inner node and per
+    leaf visited, (4 B leaf ref + 36 B vertex positions) per primitive test, 64 B ray record read + 44 B hit
+    record write per ray.  The N_* are the kernel's own counters (culled walk: children whose box the ray
+    misses are never fetched; vc only counts them)."""
+    return 8 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
+
+
+def fetched_bytes(vi, vl, vp, vc, rays):
+    """What the culled walk actually requests: an inner node is fetched as 32 B (the 8-B kd node + the two
+    12-B boxes of its children) — reported beside the roofline line, not used for it."""
     return 32 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
 
 
@@ -145,7 +150,9 @@ def main():
                                          st_count["rays_total"])),
                          float(st_count["rays_total"]), float(st_count["visits_inner"]), float(st_count["visits_leaf"]), float(st_count["visits_prim"]),
                          sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats),
-                         float(st_count["visits_culled"]), sum(s["ms_sort"] for s in stats)],
+                         float(st_count["visits_culled"]), sum(s["ms_sort"] for s in stats),
+                         float(fetched_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["visits_culled"],
+                                             st_count["rays_total"]))],
                         dtype=torch.float64, device=dev)
     tmax = vals[:1].clone()
     if world > 1:
@@ -184,7 +191,7 @@ def main():
                                                "ray_binning": v[13] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_trace_flat<false,true,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
-                         "alg_bytes_per_ray": bytes_frame / rays_frame},
+                         "alg_bytes_per_ray": bytes_frame / rays_frame, "requested_bytes_per_ray_with_child_boxes": v[14] / rays_frame},
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_rays(w, h, spp, depth):

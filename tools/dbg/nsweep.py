@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from raytracer_amd import hip, scenes
 sc = scenes.build("dragon1"); ds = hip.DeviceScene(sc.desc, 0); cam = sc.rtx_camera()
 os.environ["RTX_OVERLAP"] = "0"
-for spp in (64, 16, 4, 1):
-    for (w, h) in ((1920, 1080), (960, 540), (480, 270)):
+for spp in [int(x) for x in os.environ.get("NS_SPP", "64,16,4,1").split(",")]:
+    for (w, h) in [tuple(int(y) for y in x.split("x")) for x in os.environ.get("NS_RES", "1920x1080,960x540,480x270").split(",")]:
         best = 1e9
         for _ in range(3):
             _, _, st = ds.render(cam, hip.make_params(w, h, spp, 1), want_accum=False, want_bgr=False)
