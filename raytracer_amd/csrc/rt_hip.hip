@@ -87,6 +87,7 @@ struct rtx_scene {
     void*    ws;
     uint64_t ws_bytes;
     // second lane of rtx_render_device (two slabs in flight on two streams, see there)
+    const uint4*        d_jump_tab; // Random_Seed's jump as 8 x 256 lookups (FrameGeom::jump_tab)
     hipStream_t         aux_stream[RTX_MAX_LANES - 1];
     hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
     unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
@@ -120,6 +121,23 @@ static int upload(rtx_scene* sc, const T* host, size_t count, const T** out)
     if (count) HIPCHECK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)p;
     return RTX_OK;
+}
+
+// Random_Seed (random.c:78-85) on the host: the state after the jump, for the lookup table of the device
+static void host_jump(uint64_t a, uint64_t b, uint32_t out[4])
+{
+    uint32_t s[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    const uint32_t JUMP[4] = {0x8764000bu, 0xf542d2d3u, 0x6fa035c3u, 0x77f2db5bu};
+    uint32_t       j[4]    = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int bit = 0; bit < 32; bit++) {
+            if (JUMP[i] & (1u << bit))
+                for (int k = 0; k < 4; k++) j[k] ^= s[k];
+            const uint32_t t = s[1] << 9; // the generator's state update (random.c:31-45)
+            s[2] ^= s[0], s[3] ^= s[1], s[1] ^= s[2], s[0] ^= s[3], s[2] ^= t;
+            s[3] = (s[3] << 11) | (s[3] >> 21);
+        }
+    memcpy(out, j, sizeof j);
 }
 
 extern "C" int rtx_scene_destroy(rtx_scene* sc)
@@ -517,6 +535,16 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     UP(upload(sc, d->textures, d->n_textures, &S.tex));
     UP(upload(sc, d->tex_data, (size_t)d->tex_texels * 3, &S.tex_data));
     {
+        std::vector<uint4> tab(8 * 256);
+        for (int k = 0; k < 8; k++)
+            for (uint32_t v = 0; v < 256; v++) {
+                uint32_t j[4];
+                host_jump((uint64_t)v << (8 * k), 0, j);
+                tab[k * 256 + v] = make_uint4(j[0], j[1], j[2], j[3]);
+            }
+        UP(upload(sc, tab.data(), tab.size(), &sc->d_jump_tab));
+    }
+    {
         const uint64_t* c = nullptr;
         std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64), 0); // [80 * l ..]: queue count and work counters of lane l
         UP(upload(sc, zeros.data(), zeros.size(), &c));
@@ -555,7 +583,22 @@ struct FrameGeom {
     uint64_t seed_lo, seed_hi;
     uint32_t pixel_centres;
     uint32_t tile, slab_rows; // tile != 0: the slab is slab_rows whole rows and its paths are in tile-major pixel order
+    // Random_Seed's jump (random.c:53-76) is linear over GF(2) in the seed words: jump(a, b) = XOR over the bytes of a of
+    // jump_tab[byte position][byte value], XOR jump_b = jump(0, b).  8 lookups instead of 128 generator steps.
+    const uint4* jump_tab; // 8 x 256 entries, or NULL: do the 128 steps
+    uint32_t     jump_b[4];
 };
+
+DEV void rng_seed_tab(Rng& r, uint64_t a, const FrameGeom& g)
+{
+    uint4 j = make_uint4(g.jump_b[0], g.jump_b[1], g.jump_b[2], g.jump_b[3]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 t = g.jump_tab[k * 256 + (uint32_t)((a >> (8 * k)) & 255u)];
+        j.x ^= t.x, j.y ^= t.y, j.z ^= t.z, j.w ^= t.w;
+    }
+    r.s0 = j.x, r.s1 = j.y, r.s2 = j.z, r.s3 = j.w;
+}
 
 // Path order inside a slab of R whole rows: pixels tile by tile (TxT, row-major inside a tile), so that a
 // run of consecutive paths — what one XCD's waves hold at any time — covers a compact image region and
@@ -589,7 +632,8 @@ DEV uint32_t assigned_row(const FrameGeom& g, uint32_t k)
 DEV void camera_sample(const rtx_camera& cam, const FrameGeom& g, uint32_t xx, uint32_t yy, uint32_t s, Rng& rng, f3& o, f3& d)
 {
     uint64_t pixel = (uint64_t)yy * g.width + xx;
-    rng_seed(rng, g.seed_lo ^ (pixel * g.spp + s), g.seed_hi);
+    if (g.jump_tab) rng_seed_tab(rng, g.seed_lo ^ (pixel * g.spp + s), g);
+    else rng_seed(rng, g.seed_lo ^ (pixel * g.spp + s), g.seed_hi);
     float hf, vf;
     if (g.pixel_centres) {
         hf = ((float)xx + 0.5f) / (float)(g.width - 1);
@@ -1841,6 +1885,8 @@ static int check_params(const rtx_render_params* p, FrameGeom* g, uint32_t* rows
     g->seed_lo = p->seed_lo, g->seed_hi = p->seed_hi;
     g->pixel_centres = (p->flags & RTX_RENDER_PIXEL_CENTRES) ? 1 : 0;
     g->tile = 0, g->slab_rows = 0;
+    g->jump_tab = nullptr;
+    memset(g->jump_b, 0, sizeof g->jump_b);
     uint32_t rows = 0;
     if (g->band_rows == 0) {
         rows = p->height;
@@ -1873,6 +1919,13 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     int       rc   = check_params(p, &g, &rows);
     if (rc != RTX_OK) return rc;
     HIPCHECK(hipSetDevice(sc->device));
+    {
+        const char* e = getenv("RTX_JUMP_TABLE"); // 0: the literal 128-step jump in raygen (the tests compare the two)
+        if (!e || atoi(e) != 0) {
+            g.jump_tab = sc->d_jump_tab;
+            host_jump(0, p->seed_hi, g.jump_b);
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     rtx_stats   local;
     memset(&local, 0, sizeof local);

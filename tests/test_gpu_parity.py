@@ -294,3 +294,17 @@ def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, mon
         assert np.array_equal(bgr, frames[0][0]) and same_bits(acc, frames[0][1])
         assert st["rays_at_depth"] == frames[0][2]["rays_at_depth"]
     assert frames[0][2]["passes"] == 1 and frames[1][2]["passes"] == 2 and frames[2][2]["passes"] > 4
+
+
+@pytest.mark.gpu
+def test_table_driven_seed_jump_equals_the_128_steps(built_scenes, device_scenes, monkeypatch):
+    """raygen seeds each path with Random_Seed (random.c:78-85); its 128-step jump is linear over GF(2), so the kernel
+    looks it up (8 table entries XORed).  Same frame, bit for bit, as with the literal jump — for odd seeds too."""
+    sc, ds = built_scenes("teapot"), device_scenes("teapot")
+    for seed in ((1, 2), (0xFFFFFFFFFFFFFFFF, 0x8000000000000001), (0x0123456789ABCDEF, 0)):
+        frames = []
+        for tab in ("1", "0"):
+            monkeypatch.setenv("RTX_JUMP_TABLE", tab)
+            frames.append(ds.render(sc.rtx_camera(), hip.make_params(160, 90, 4, 3, seed=seed)))
+        assert np.array_equal(frames[0][0], frames[1][0]) and same_bits(frames[0][1], frames[1][1])
+        assert frames[0][2]["rays_at_depth"] == frames[1][2]["rays_at_depth"]
