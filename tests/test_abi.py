@@ -43,6 +43,17 @@ def test_hip_library_fails_loudly_without_a_device_or_with_bad_arguments(built_s
         assert L.rtx_scene_create(built_scenes("materials").desc, 0, C.byref(h)) == -2
     assert L.rtx_scene_create(None, 0, C.byref(h)) < 0
     assert L.rtx_render(None, None, None, None, None, None) == -1
+    # the entry points added for the §8f rows refuse bad arguments before they look for a device
+    assert L.rtx_render_progressive(None, None, None, 0, None, None, None, None, None) == -1
+    assert L.rtx_render_progressive(None, None, None, 4, None, None, None, None, None) == -1
+    t = host.rtx_kd_tree()
+    assert L.rtx_kd_build(0, None, 0, 10, None, C.byref(t)) == -1 and b"rtx_kd_build" in L.rtx_last_error()
+    L.rtx_kd_free(C.byref(t))  # an empty tree may be freed
+    L.rtx_kd_free(None)
+    if rc != 0:
+        import numpy as np
+        box = np.array([[0, 0, 0, 1, 1, 1]], np.float32)
+        assert L.rtx_kd_build(0, box.ctypes.data_as(C.POINTER(C.c_float)), 1, 8, box.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t)) == -2
 
 
 def test_product_never_touches_the_oracle():
