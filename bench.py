@@ -168,12 +168,13 @@ def main():
         alg_per_launch = bytes_frame / world / max(launches_per_frame, 1)
         ms_per_launch = ms_trace / max(launches, 1)
         achieved = alg_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        traffic = None
+        traffic, counters = None, {}
         tj = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tj):  # measured in a separate rocprofv3 --pmc run of this same command (profiles/)
             tr = json.load(open(tj))
             if tr.get("workload") == "%s %dx%d %dspp d%d" % (args.scene, args.width, args.height, args.spp, args.depth) and world == 1:
                 traffic = tr.get("hbm_bytes_per_launch")
+                counters = {k: tr[k] for k in ("hbm_gbs", "l2_hit_rate", "valu_busy", "valu_lane_utilisation") if tr.get(k) is not None}
         out = {
             "metric": "Mrays/s and s/frame, dragon.obj 1080p 64spp, at 1/2/4/8 MI355X",
             "value": rays_total / t / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,7 +192,10 @@ def main():
                                                "ray_binning": v[13] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_trace_flat<false,true,true>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
-                         "alg_bytes_per_ray": bytes_frame / rays_frame, "requested_bytes_per_ray_with_child_boxes": v[14] / rays_frame},
+                         "alg_bytes_per_ray": bytes_frame / rays_frame, "requested_bytes_per_ray_with_child_boxes": v[14] / rays_frame,
+                         # rocprofv3 --pmc passes of this same command (profiles/, tools/profile_round.sh): HBM-side GB/s of the
+                         # kernel, L2 (TCC) hit rate, share of SIMD cycles issuing vector instructions, active lanes per instruction
+                         "counters": counters},
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_rays(w, h, spp, depth):

@@ -32,21 +32,35 @@ pass() { # name counters...
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY
+pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE
 rm -rf "$OUT/trace"
 # HBM-side traffic of the closest-hit kernel per launch (timed frame = the last 8 k_trace dispatches):
 # FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
 python3 - "$OUT" <<'PY'
-import json, sys
+import csv, json, sys
 out = sys.argv[1]
-def col(name):
-    rows = [l.split() for l in open("%s/pmc_%s.txt" % (out, name)).read().splitlines()[1:]]
-    return [float(r[1]) for r in rows][-8:]
-f, w = col("fetch"), col("write")
+def table(name):
+    lines = open("%s/pmc_%s.txt" % (out, name)).read().splitlines()
+    cols = lines[0].split()[1:]
+    rows = [[float(x) for x in l.split()[1:]] for l in lines[1:]][-8:]  # the timed frame's 8 k_trace dispatches
+    return {c: [r[i] for r in rows] for i, c in enumerate(cols)}
+f, w, tcc, sq = table("fetch")["FETCH_SIZE"], table("write")["WRITE_SIZE"], table("tcc"), table("sq")
 per_launch = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
-json.dump({"workload": "dragon1 1920x1080 64spp d8", "hbm_bytes_per_launch": sum(per_launch) / len(per_launch),
-           "fetch_size_kib": f, "write_size_kib": w, "note": "per k_trace launch of one frame; FETCH_SIZE x2 (gfx950), + WRITE_SIZE, x1024"},
-          open("%s/traffic.json" % out, "w"), indent=1)
-print(open("%s/traffic.json" % out).read())
+# mean duration of the timed kernel from the kernel-trace run of the same command
+ms = None
+for r in csv.DictReader(open("%s/kernel_stats.csv" % out)):
+    if r["Name"].startswith("void k_trace_flat<false"):
+        ms = float(r["AverageNs"]) / 1e6
+simd_cycles = [g / 8.0 * 1024.0 for g in sq["GRBM_GUI_ACTIVE"]]  # GRBM_GUI_ACTIVE sums the 8 XCDs; 256 CUs x 4 SIMDs
+d = {"workload": "dragon1 1920x1080 64spp d8", "hbm_bytes_per_launch": sum(per_launch) / len(per_launch),
+     "fetch_size_kib": f, "write_size_kib": w, "note": "per k_trace launch of one frame; FETCH_SIZE x2 (gfx950), + WRITE_SIZE, x1024",
+     "ms_per_launch_kernel_trace": ms,
+     "hbm_gbs": (sum(per_launch) / len(per_launch)) / (ms * 1e-3) / 1e9 if ms else None,
+     "l2_hit_rate": sum(tcc["TCC_HIT_sum"]) / sum(tcc["TCC_REQ_sum"]),
+     "valu_busy": sum(4.0 * x for x in sq["SQ_INSTS_VALU"]) / sum(simd_cycles),
+     "valu_busy_per_launch": [4.0 * x / c for x, c in zip(sq["SQ_INSTS_VALU"], simd_cycles)],
+     "valu_lane_utilisation": sum(sq["SQ_THREAD_CYCLES_VALU"]) / (64.0 * sum(sq["SQ_ACTIVE_INST_VALU"]))}
+json.dump(d, open("%s/traffic.json" % out, "w"), indent=1)
+print(json.dumps({k: v for k, v in d.items() if not isinstance(v, list)}, indent=1))
 PY
 echo done
