@@ -2067,7 +2067,8 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         next_px += a.npx;
         local.passes++;
         local.camera_paths += a.n;
-        HIPCHECK(hipMemsetAsync(a.result, 0, cap * 12, a.s));
+        // (no clearing of the result slab: every path writes its slot exactly once — on a miss, when its material ends
+        // it, or at the last depth — before the slab is resolved)
         a.gs = g; // tile-major path order when the slab is made of whole rows
         if (a.px0 % g.width == 0 && a.npx % g.width == 0 && a.npx / g.width >= 2 * PATH_TILE) a.gs.tile = PATH_TILE, a.gs.slab_rows = (uint32_t)(a.npx / g.width);
         a.cur = 0, a.qin = soa(a, 0), a.depth = 0; // SoA out of raygen / shade, AoS out of the binning pass
