@@ -1961,11 +1961,13 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes + 255) & ~255ull;
     char*          ws         = nullptr;
     if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
-    static int sort_depth = -1; // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never)
-    if (sort_depth < 0) {
-        const char* e = getenv("RTX_SORT_DEPTH");
-        sort_depth    = e ? atoi(e) : 2;
-    }
+    // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never).  Read per call: the tests switch it.
+    const char* sd_env     = getenv("RTX_SORT_DEPTH");
+    const int   sort_depth = sd_env ? atoi(sd_env) : 2;
+    // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~4 M rays the closest-hit
+    // pass it speeds up is too short to pay that back (tools/dbg/bands.py: a rank's share under an 8-way split)
+    const char*     sm_env  = getenv("RTX_SORT_MIN");
+    const long long bin_min = sm_env ? atoll(sm_env) : (4ll << 20);
     static int sort_every = 0; // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
     if (sort_every == 0) {
         const char* e = getenv("RTX_SORT_EVERY");
@@ -2048,7 +2050,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         local.trace_launches++;
         HIPCHECK(hipMemsetAsync(a.d_cnt, 0, sizeof(unsigned long long), a.s));
         a.last = depth + 1 == p->max_depth;
-        a.bin  = !a.last && sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && a.n >= 65536;
+        a.bin  = !a.last && sort_depth > 0 && (int)depth + 1 >= sort_depth && ((int)depth + 1 - sort_depth) % sort_every == 0 && (long long)a.n >= bin_min;
         if (a.bin) HIPCHECK(hipMemsetAsync(a.bin_cnt, 0, bin_bytes, a.s));
         r = timed(2, depth, a.s, [&] {
             hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, a.s, sc->dev, a.qin, a.hits, a.n, soa(a, a.cur ^ 1), a.d_cnt,

@@ -308,3 +308,22 @@ def test_table_driven_seed_jump_equals_the_128_steps(built_scenes, device_scenes
             frames.append(ds.render(sc.rtx_camera(), hip.make_params(160, 90, 4, 3, seed=seed)))
         assert np.array_equal(frames[0][0], frames[1][0]) and same_bits(frames[0][1], frames[1][1])
         assert frames[0][2]["rays_at_depth"] == frames[1][2]["rays_at_depth"]
+
+
+@pytest.mark.gpu
+def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monkeypatch):
+    """Between bounce passes the surviving rays are counting-sorted by origin cell and direction octant (big queues
+    only by default).  Queue order does not enter any result: frames with binning forced on for every queue, off,
+    and at the default threshold are the same bits; forced on, it really ran."""
+    sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
+    p = hip.make_params(480, 270, 8, 8, seed=(7, 8))
+    frames = {}
+    for name, env in (("forced", {"RTX_SORT_MIN": "1"}), ("off", {"RTX_SORT_DEPTH": "0"}), ("default", {})):
+        for k in ("RTX_SORT_MIN", "RTX_SORT_DEPTH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        frames[name] = ds.render(sc.rtx_camera(), p)
+    for name in ("off", "default"):
+        assert same_bits(frames[name][1], frames["forced"][1]) and frames[name][2]["rays_at_depth"] == frames["forced"][2]["rays_at_depth"]
+    assert frames["forced"][2]["ms_sort"] > 0.0 and frames["off"][2]["ms_sort"] == 0.0
