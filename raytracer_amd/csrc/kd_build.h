@@ -236,8 +236,8 @@ __global__ __launch_bounds__(KD_BLOCK) void k_kd_emit(const KdNode* __restrict__
             if (w < wave) pl += s_wl[w], pr += s_wr[w];
             tl += s_wl[w], tr += s_wr[w];
         }
-        if (fl) next_refs[lbegin + pl] = r;
-        if (fr) next_refs[rbegin + pr] = r;
+        if (fl && pl < d.n_left) next_refs[lbegin + pl] = r;   // (the counts always match for finite boxes with min <= max,
+        if (fr && pr < d.n_right) next_refs[rbegin + pr] = r; //  which rtx_kd_build insists on; the bounds keep a bug from faulting)
         doneL += tl, doneR += tr;
         __syncthreads();
     }
@@ -282,6 +282,15 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
     if (!box_min_max || !world_min_max || !out || n == 0) return fail(RTX_E_INVALID, "rtx_kd_build: null argument or no boxes");
     if (n > 0x3FFFFFFFull) return fail(RTX_E_LIMIT, "rtx_kd_build: more than 2^30 primitives (kdtree.c:412)");
     memset(out, 0, sizeof *out);
+    for (uint64_t i = 0; i < n; i++) { // the kernels assume finite boxes with min <= max (CreateKDBBs pads by +-1e-4: min < max)
+        const float* b = box_min_max + 6 * i;
+        for (int a = 0; a < 3; a++)
+            if (!(b[a] <= b[3 + a]) || !std::isfinite(b[a]) || !std::isfinite(b[3 + a]))
+                return fail(RTX_E_INVALID, "rtx_kd_build: box %llu is not finite or has min > max", (unsigned long long)i);
+    }
+    for (int a = 0; a < 3; a++)
+        if (!(world_min_max[a] <= world_min_max[3 + a]) || !std::isfinite(world_min_max[a]) || !std::isfinite(world_min_max[3 + a]))
+            return fail(RTX_E_INVALID, "rtx_kd_build: the world box is not finite or has min > max");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RTX_E_NO_DEVICE, "rtx_kd_build: no HIP device visible");
     if (device < 0 || device >= ndev) return fail(RTX_E_NO_DEVICE, "rtx_kd_build: device %d of %d", device, ndev);

@@ -48,10 +48,15 @@ def test_hip_library_fails_loudly_without_a_device_or_with_bad_arguments(built_s
     assert L.rtx_render_progressive(None, None, None, 4, None, None, None, None, None) == -1
     t = host.rtx_kd_tree()
     assert L.rtx_kd_build(0, None, 0, 10, None, C.byref(t)) == -1 and b"rtx_kd_build" in L.rtx_last_error()
+    import numpy as np
+    bad = np.array([[0, 0, 0, 1, 1, 1], [0, 0, 2, 1, 1, 1], [0, 0, 0, 1, np.nan, 1]], np.float32)  # min > max, NaN
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    for k in (1, 2):
+        assert L.rtx_kd_build(0, fp(bad[[0, k]].copy()), 2, 9, fp(np.array([0, 0, 0, 1, 1, 2], np.float32)), C.byref(t)) == -1
+        assert b"not finite or has min > max" in L.rtx_last_error()
     L.rtx_kd_free(C.byref(t))  # an empty tree may be freed
     L.rtx_kd_free(None)
     if rc != 0:
-        import numpy as np
         box = np.array([[0, 0, 0, 1, 1, 1]], np.float32)
         assert L.rtx_kd_build(0, box.ctypes.data_as(C.POINTER(C.c_float)), 1, 8, box.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t)) == -2
 
