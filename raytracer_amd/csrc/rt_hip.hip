@@ -1504,29 +1504,42 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
 }
 
 // exclusive prefix sum of the 2^BIN_BITS counters, in place (one block)
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts)
+// Exclusive prefix sums of the 2^BIN_BITS bin counts, in two short launches (one 1024-thread block walking all of them
+// took 100 us, on the critical path of every binned pass): each block scans its own 1024 counts in place and
+// leaves their total in chunk[block]; one more block turns the chunk totals into chunk bases, which the scatter adds.
+#define BIN_CHUNKS ((1u << BIN_BITS) / 1024u)
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ chunk)
 {
-    __shared__ uint32_t s_sum[1024];
-    const uint32_t per = (1u << BIN_BITS) / 1024u, b0 = threadIdx.x * per;
-    uint32_t       t = 0;
-    for (uint32_t k = 0; k < per; k++) t += counts[b0 + k];
-    s_sum[threadIdx.x] = t;
+    __shared__ uint32_t s_w[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i   = blockIdx.x * 1024u + tid;
+    const uint32_t c   = counts[i];
+    const uint32_t inc = wave_scan_add(c);
+    if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-        uint32_t v = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < wave) before += s_w[w];
+        total += s_w[w];
     }
-    uint32_t run = s_sum[threadIdx.x] - t;
-    for (uint32_t k = 0; k < per; k++) {
-        uint32_t c     = counts[b0 + k];
-        counts[b0 + k] = run;
-        run += c;
-    }
+    counts[i] = before + inc - c;
+    if (tid == 0) chunk[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(BIN_CHUNKS) void k_bin_scan_chunks(uint32_t* __restrict__ chunk)
+{
+    __shared__ uint32_t s_w[BIN_CHUNKS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c   = chunk[tid];
+    const uint32_t inc = wave_scan_add(c);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += s_w[w];
+    chunk[tid] = before + inc - c;
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ keys, Queue qout)
+__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk,
+                                                     const uint32_t* __restrict__ keys, Queue qout)
 {
     uint64_t       i      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool     active = i < n;
@@ -1534,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint
     uint32_t       base;
     const uint32_t rank = wave_group_add(offsets, key, active, base);
     if (!active) return;
-    const uint64_t pos = (uint64_t)base + rank;
+    const uint64_t pos = (uint64_t)base + chunk[key >> 10] + rank;
     // the destination is an AoS queue: one 64-byte record = one line per path, instead of 14 dwords on 14 lines
     uint32_t w[Q_RECORD];
 #pragma unroll
@@ -1957,7 +1970,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     if (cap > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "spp too large for one slab");
 
     const uint64_t qbytes     = cap * Q_RECORD * 4;
-    const uint64_t bin_bytes  = (4ull << BIN_BITS);
+    const uint64_t bin_bytes  = (4ull << BIN_BITS) + 4ull * BIN_CHUNKS; // counts, then the chunk totals of the scan
     const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes + 255) & ~255ull;
     char*          ws         = nullptr;
     if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
@@ -2083,8 +2096,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         a.qin = soa(a, a.cur);
         if (a.bin && a.n > 0) {
             int r = timed(4, a.depth, a.s, [&] {
-                hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, a.s, a.bin_cnt);
-                hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, a.qin, a.n, a.bin_cnt, a.bin_keys, aos(a, a.cur ^ 1));
+                uint32_t* chunk = a.bin_cnt + (1u << BIN_BITS);
+                hipLaunchKernelGGL(k_bin_scan, dim3(BIN_CHUNKS), dim3(1024), 0, a.s, a.bin_cnt, chunk);
+                hipLaunchKernelGGL(k_bin_scan_chunks, dim3(1), dim3(BIN_CHUNKS), 0, a.s, chunk);
+                hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, a.qin, a.n, a.bin_cnt, chunk, a.bin_keys,
+                                   aos(a, a.cur ^ 1));
             });
             if (r != RTX_OK) return r;
             a.cur ^= 1;
