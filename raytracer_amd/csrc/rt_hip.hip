@@ -1365,7 +1365,7 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
                                                        unsigned long long* out_count, unsigned long long* shaded_count,
                                                        float* __restrict__ result, uint64_t rcap, int last,
-                                                       uint32_t* __restrict__ bin_cnt, uint32_t* __restrict__ bin_keys)
+                                                       uint32_t* __restrict__ bin_cnt, uint2* __restrict__ bin_keys)
 {
     __shared__ uint32_t s_wave_cnt[SHADE_BLOCK / 64], s_wave_shaded[SHADE_BLOCK / 64];
     __shared__ uint64_t s_base;
@@ -1438,14 +1438,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
         qout.u(Q_PID, pos) = pid;
     }
     if (bin_cnt) { // first half of the binning pass (k_bin_scan / k_bin_scatter follow): key and histogram
+        // The histogram's atomic already hands every ray a slot of its own inside its bin (old count + rank in the wave's
+        // group): kept beside the key, so that the scatter needs no second round of atomics.
         const uint32_t key = alive ? ray_bin(S, o2, d2) : 0u;
+        uint32_t       base;
+        const uint32_t grank = wave_group_add(bin_cnt, key, alive, base); // one atomic per wave and key
         if (alive) {
             uint64_t pos = s_base + rank;
             for (uint32_t w = 0; w < wave; w++) pos += s_wave_cnt[w];
-            bin_keys[pos] = key;
+            bin_keys[pos] = make_uint2(key, base + grank);
         }
-        uint32_t base;
-        (void)wave_group_add(bin_cnt, key, alive, base); // one atomic per wave and key
     }
 }
 
@@ -1503,7 +1505,6 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
     return rank;
 }
 
-// exclusive prefix sum of the 2^BIN_BITS counters, in place (one block)
 // Exclusive prefix sums of the 2^BIN_BITS bin counts, in two short launches (one 1024-thread block walking all of them
 // took 100 us, on the critical path of every binned pass): each block scans its own 1024 counts in place and
 // leaves their total in chunk[block]; one more block turns the chunk totals into chunk bases, which the scatter adds.
@@ -1538,16 +1539,13 @@ __global__ __launch_bounds__(BIN_CHUNKS) void k_bin_scan_chunks(uint32_t* __rest
     chunk[tid] = before + inc - c;
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk,
-                                                     const uint32_t* __restrict__ keys, Queue qout)
+__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk,
+                                                     const uint2* __restrict__ keys, Queue qout)
 {
-    uint64_t       i      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool     active = i < n;
-    const uint32_t key    = active ? keys[i] : 0u;
-    uint32_t       base;
-    const uint32_t rank = wave_group_add(offsets, key, active, base);
-    if (!active) return;
-    const uint64_t pos = (uint64_t)base + chunk[key >> 10] + rank;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2    ks  = keys[i]; // bin, slot inside the bin
+    const uint64_t pos = (uint64_t)offsets[ks.x] + chunk[ks.x >> 10] + ks.y;
     // the destination is an AoS queue: one 64-byte record = one line per path, instead of 14 dwords on 14 lines
     uint32_t w[Q_RECORD];
 #pragma unroll
@@ -1971,7 +1969,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
 
     const uint64_t qbytes     = cap * Q_RECORD * 4;
     const uint64_t bin_bytes  = (4ull << BIN_BITS) + 4ull * BIN_CHUNKS; // counts, then the chunk totals of the scan
-    const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 4 + bin_bytes + 255) & ~255ull;
+    const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 8 + bin_bytes + 255) & ~255ull;
     char*          ws         = nullptr;
     if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
     // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never).  Read per call: the tests switch it.
@@ -2026,7 +2024,8 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         float*              qb[2];
         Hits                hits;
         float*              result;
-        uint32_t *          bin_keys, *bin_cnt;
+        uint2*              bin_keys;
+        uint32_t*           bin_cnt;
         unsigned long long *d_cnt, *work, *h_alive;
         uint64_t            px0, npx, n;
         FrameGeom           gs;
@@ -2040,9 +2039,9 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         L[l].s        = l == 0 ? st : sc->aux_stream[l - 1];
         L[l].qb[0]    = (float*)w, L[l].qb[1] = (float*)(w + qbytes);
         L[l].hits     = Hits{(uint32_t*)(w + 2 * qbytes), cap};
-        L[l].result   = (float*)(w + 2 * qbytes + cap * 16);
-        L[l].bin_keys = (uint32_t*)(w + 2 * qbytes + cap * 16 + cap * 12);
-        L[l].bin_cnt  = (uint32_t*)(w + 2 * qbytes + cap * 16 + cap * 12 + cap * 4);
+        L[l].bin_keys = (uint2*)(w + 2 * qbytes + cap * 16); // 8-byte entries on a 16-byte boundary
+        L[l].result   = (float*)(w + 2 * qbytes + cap * 16 + cap * 8);
+        L[l].bin_cnt  = (uint32_t*)(w + 2 * qbytes + cap * 16 + cap * 8 + cap * 12);
         L[l].d_cnt    = (unsigned long long*)&sc->d_counters[80 * l + 6];
         L[l].work     = (unsigned long long*)&sc->d_counters[80 * l + 16];
         L[l].h_alive  = sc->h_alive + l;
