@@ -1060,14 +1060,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_flat(SceneDev S, const fl
                 // part): the waves of an XCD drain their own part front to back, so the rays resident on an XCD
                 // are neighbours in path order (= in the image, see slab_pixel) and share that XCD's L2.  A wave
                 // whose part is empty moves on to the next one; after 8 empty parts it is done.
+                // (Grabs of at most 128 rays: with 1024-ray grabs a launch ended with some waves a whole grab behind the
+                // others — 104 -> 95 ms per frame; smaller ones cost the primary pass more in atomics than they balance.
+                // Shrinking the grabs as a part drains was no better than the fixed size.)
                 while (parts_left > 0) {
                     const uint64_t     pb = part_begin(n, part), pe = part_begin(n, part + 1);
                     unsigned long long base = 0;
+                    const uint64_t     grab = chunk;
                     if (lane == 0) base = atomicAdd(work + 8 * part, (unsigned long long)chunk);
                     base = wave_bcast_u64(base) + pb;
                     if (base < pe) {
                         next = base;
-                        end  = base + chunk < pe ? base + chunk : pe;
+                        end  = base + grab < pe ? base + grab : pe;
                         break;
                     }
                     part = (part + 1) & 7u;
@@ -1790,7 +1794,8 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     const uint64_t waves    = (uint64_t)resident * (bs / 64);
     // chunk: about 8 grabs per wave on big queues, never below one wave's worth
     uint64_t chunk = n / (waves * 8);
-    chunk          = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+    chunk          = chunk < 64 ? 64 : (chunk > 128 ? 128 : chunk);
+    if (const char* e = getenv("RTX_TRACE_CHUNK")) chunk = std::max(16, atoi(e)); // experiments
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
     HIPCHECK(hipGetLastError());
