@@ -1954,15 +1954,14 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         if (stats) *stats = local;
         return RTX_OK;
     }
-    // Lanes.  A closest-hit launch ends with a tail: the queue is empty and the longest rays still walk (about a
-    // microsecond per node step with the chip nearly idle: 0.8-1.7 ms per launch whatever the queue's size).  On a
-    // whole 1080p / 64 spp frame that is 6 % of the time; on a rank's share of a frame split over 8 GPUs it is a third.
-    // Below ~100 M paths the assigned pixels are therefore cut into two halves that go through the bounce loop on two
-    // streams, a pass of one overlapping the tail of the other (RTX_OVERLAP=0/1 forces it off/on).  The halves are
-    // independent slabs, so the frame is the same, bit for bit.
+    // Lanes (RTX_OVERLAP=1..3, off by default).  The assigned pixels can be cut into 2-4 parts that go through the bounce
+    // loop on as many streams, a pass of one overlapping the end of another's launch.  The parts are independent slabs,
+    // so the frame is the same, bit for bit (tests).  It paid 4-8 % on a rank's share of a frame split over 2-8 GPUs
+    // while a launch ended with some waves a whole 1024-ray grab behind the others; with 128-ray grabs what is left
+    // of a launch's end is its longest ray, which overlap cannot shorten, and one lane is as fast (tools/dbg/bands.py).
     const char* ov_env  = getenv("RTX_OVERLAP"); // read per call: the tests switch it
     const int   overlap = ov_env ? atoi(ov_env) : -1;
-    int lanes = overlap >= 1 ? std::min(overlap + 1, RTX_MAX_LANES) : (overlap == -1 && total <= (100ull << 20)) ? 2 : 1;
+    int lanes = overlap >= 1 ? std::min(overlap + 1, RTX_MAX_LANES) : 1; // off unless asked for: see above
     if ((uint32_t)lanes > rows) lanes = (int)rows;
     // slab sizing: whole pixels, at most `budget` paths in flight
     uint64_t budget = p->max_paths_in_flight ? p->max_paths_in_flight : (160ull << 20); // whole 1080p/64spp frame: 133 M paths, 18.6 GB of 288
