@@ -203,6 +203,8 @@ def main():
                 s = ds.render_device(cam, hip.make_params(w, h, spp, depth, seed=(1, 2)), a.data_ptr(), stream)
                 return s["rays_total"]
             out["cpu_baseline"] = cpu_baseline(args.scene, 1280, 720, args.spp, args.depth, gpu_rays)
+            if out["cpu_baseline"].get("value"):  # the same frame at the CPU's measured rate (the sample is 4/9 of its pixels)
+                out["cpu_baseline"]["s_per_full_frame_extrapolated"] = rays_frame / (out["cpu_baseline"]["value"] * 1e6)
         if args.save_bmp:
             from raytracer_amd import host
             import ctypes as C
