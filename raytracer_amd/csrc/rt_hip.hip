@@ -1793,10 +1793,9 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     if (!work) work = (unsigned long long*)&sc->d_counters[16]; // 8 part counters, 64 B apart
     HIPCHECK(hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), st));
     const unsigned resident = sc->persist_blocks[slot];
-    const uint64_t waves    = (uint64_t)resident * (bs / 64);
-    // chunk: about 8 grabs per wave on big queues, never below one wave's worth
-    uint64_t chunk = n / (waves * 8);
-    chunk          = chunk < 64 ? 64 : (chunk > 128 ? 128 : chunk);
+    // grab size: 160 rays on the big coherent queues (fewer atomics, neighbouring rays stay on one wave), one wave's worth
+    // on the smaller ones, where balance at the end of the launch is worth more (sweep: tools/dbg, RTX_TRACE_CHUNK)
+    uint64_t chunk = n >= (64ull << 20) ? 160 : 64;
     if (const char* e = getenv("RTX_TRACE_CHUNK")) chunk = std::max(16, atoi(e)); // experiments
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
