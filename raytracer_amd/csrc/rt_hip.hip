@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
     // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
     // enough lanes wait for it (or nothing else can run); lanes in the other state simply keep their place.
     const uint32_t leaf_min = tune & 0xFFu, inner_min = (tune >> 8) & 0xFFu, refill_min = (tune >> 16) & 0xFFu;
+    // the root's box is tested when a ray is loaded — unless the caller knows the rays start on the scene's surfaces
+    // (bounce passes), where that test never fails and the children's tests one step later do its work
+    const bool     root_test = !((tune >> 25) & 1u);
     const uint32_t lane    = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -1122,7 +1125,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
                     sp    = 0;
                     base  = 0;
                     state = ST_INNER;
-                    if (CULL && cullOK && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o, inv, RTX_INF)) {
+                    if (CULL && root_test && cullOK && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o, inv, RTX_INF)) {
                         // the ray misses the box of everything in the tree: finished here, the lane stays free
                         if (COUNT) vis.culled++;
                         write_hit(HIT_MISS, RTX_INF, 0.0f, 0.0f);
@@ -1743,7 +1746,7 @@ static int trace_variant()
 }
 
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
-                        bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr)
+                        bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false)
 {
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
@@ -1798,7 +1801,8 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     uint64_t chunk = n >= (64ull << 20) ? 160 : 64;
     if (const char* e = getenv("RTX_TRACE_CHUNK")) chunk = std::max(16, atoi(e)); // experiments
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters, tune);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
+                       tune | (bounce_rays && !count ? 1u << 25 : 0u));
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
@@ -2061,7 +2065,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         local.rays_at_depth[depth] += a.n;
         local.rays_total += a.n;
         int r = timed(1, depth, a.s, [&] {
-            (void)launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work);
+            (void)launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
         });
         if (r != RTX_OK) return r;
         local.trace_launches++;
