@@ -2016,6 +2016,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     struct Span { int a, b, kind; uint32_t depth; };
     std::vector<Span> spans;
     auto timed = [&](int kind, uint32_t depth, hipStream_t s, auto&& launch) -> int {
+        if (nev + 2 > (int)(sizeof sc->ev / sizeof sc->ev[0])) { // a frame cut into very many slabs: the rest goes untimed
+            launch();
+            HIPCHECK(hipGetLastError());
+            return RTX_OK;
+        }
         hipEvent_t a, b;
         int        ia = nev, ib = nev + 1, r;
         if ((r = get_event(sc, nev++, &a)) != RTX_OK) return r;

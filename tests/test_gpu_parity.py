@@ -327,3 +327,23 @@ def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monke
     for name in ("off", "default"):
         assert same_bits(frames[name][1], frames["forced"][1]) and frames[name][2]["rays_at_depth"] == frames["forced"][2]["rays_at_depth"]
     assert frames["forced"][2]["ms_sort"] > 0.0 and frames["off"][2]["ms_sort"] == 0.0
+
+
+@pytest.mark.gpu
+def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monkeypatch):
+    """Frames whose sizes fit no tile, wave or slab boundary: one launch, tiny slabs, several lanes and a forced
+    binning pass all give the same bits and trace the same rays."""
+    sc, ds = built_scenes("materials"), device_scenes("materials")
+    for (w, h, spp, depth) in ((3, 2, 1, 1), (33, 17, 3, 5), (257, 129, 2, 4), (5, 7, 64, 3), (64, 64, 5, 8)):
+        base = None
+        for env, mpf in (({}, 0), ({}, 777), ({"RTX_OVERLAP": "3"}, 0), ({"RTX_OVERLAP": "2", "RTX_SORT_MIN": "1"}, 1500), ({"RTX_SORT_MIN": "1"}, 0)):
+            for k in ("RTX_OVERLAP", "RTX_SORT_MIN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            bgr, acc, st = ds.render(sc.rtx_camera(), hip.make_params(w, h, spp, depth, seed=(9, w), max_paths_in_flight=mpf))
+            if base is None:
+                base = (bgr, acc, st)
+                assert st["rays_at_depth"][0] == w * h * spp
+            else:
+                assert np.array_equal(bgr, base[0]) and same_bits(acc, base[1]) and st["rays_at_depth"] == base[2]["rays_at_depth"], (w, h, spp, depth, env, mpf)
