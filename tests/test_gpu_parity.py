@@ -347,3 +347,48 @@ def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monk
                 assert st["rays_at_depth"][0] == w * h * spp
             else:
                 assert np.array_equal(bgr, base[0]) and same_bits(acc, base[1]) and st["rays_at_depth"] == base[2]["rays_at_depth"], (w, h, spp, depth, env, mpf)
+
+
+@pytest.mark.parametrize("scene", ["teapot", "materials"])
+def test_awkward_rays_match_the_oracle(built_scenes, device_scenes, scene):
+    """Rays on the awkward spots — directions exactly along or parallel to axes (with -0.0), origins on the faces of
+    the culling boxes, origins far outside, non-unit, infinite and NaN directions: same ids from the kernel as from
+    the CPU restatement of the reference's recursion, same bits wherever the hit is finite, and no fault."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    qbox, info = hip.cull_data(sc.desc)
+    boxes = hip.cull_boxes_world(qbox, info)
+    boxes = boxes[np.isfinite(boxes).all(axis=1)].astype(np.float32)
+    rng = np.random.default_rng(17)
+    n = 30000
+    node = rng.integers(0, len(boxes), n)
+    lo, hi = boxes[node, :3], boxes[node, 3:]
+    o = (lo + (hi - lo) * rng.random((n, 3), dtype=np.float32)).astype(np.float32)
+    face = rng.integers(0, 12, n)
+    for a in range(3):
+        o[face == a, a] = lo[face == a, a]
+        o[face == 3 + a, a] = hi[face == 3 + a, a]
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    par = rng.integers(0, 4, n)
+    for a in range(3):
+        d[par == a, a] = np.where(rng.random((par == a).sum()) < 0.5, 0.0, -0.0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = n // 10
+    d[:k] = 0.0
+    d[np.arange(k), rng.integers(0, 3, k)] = np.where(rng.random(k) < 0.5, 1.0, -1.0)
+    o[k:2 * k] = (info[:3] + 4.0 * np.sqrt(info[3]) * d[k:2 * k]).astype(np.float32)  # outside the culling radius, looking back
+    d[k:2 * k] *= -1.0
+    d[2 * k:2 * k + 500, 0] = np.nan
+    d[2 * k + 500:2 * k + 1000] *= 1.7
+    d[2 * k + 1000:2 * k + 1500, 1] = np.inf
+    d[2 * k + 1500:2 * k + 2000] = 0.0
+    o[2 * k + 2000:2 * k + 2200, 2] = np.nan
+    want = O.trace(sc.desc, o, d, unit_dir=True)
+    got = ds.trace_closest(o, d, flags=hip.RTX_TRACE_UNIT_DIR)
+    lit = ds.trace_closest(o, d, flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_TRACE_LITERAL)
+    for g in (got, lit):
+        assert np.array_equal(g["prim_id"], want["prim_id"])
+        ok = (want["prim_id"] != 0xFFFFFFFF) & np.isfinite(want["t"])
+        assert same_bits(g["t"][ok], want["t"][ok]) and np.array_equal(g["front"][ok], want["front"][ok])
+        fin = ok & np.isfinite(want["position"]).all(axis=1) & np.isfinite(want["normal"]).all(axis=1)
+        assert same_bits(g["position"][fin], want["position"][fin]) and same_bits(g["normal"][fin], want["normal"][fin])
+    assert (want["prim_id"] != 0xFFFFFFFF).mean() > 0.2
