@@ -143,8 +143,13 @@ typedef struct Mesh Mesh;
 Mesh* Mesh_New(void);                               /* mesh.c:25 */
 void  Mesh_Delete(Mesh* mesh);                      /* mesh.c:46 */
 bool  Mesh_Import_OBJ(Mesh* mesh, FILE* fd);        /* mesh.c:87 */
+/* The same importer over a file in memory / at a path, parsed by several threads (RTX_HOST_THREADS, default the
+ * host's cores up to 16; one thread below 1 MB): same triangles in the same order, same quirks (512-byte fgets
+ * chunks, the last line examined twice), same errors as Mesh_Import_OBJ.  SURVEY 8(f) rank 3. */
+bool  Mesh_Import_OBJ_Memory(Mesh* mesh, const char* data, size_t size);
 bool  Mesh_Import_OBJ_Path(Mesh* mesh, const char* path);
-void  Mesh_AddToScene(Mesh* mesh, Scene* scene);    /* mesh.c:67 */
+void  Mesh_AddToScene(Mesh* mesh, Scene* scene);    /* mesh.c:67; triangles go straight into the scene's
+                                                       compact pool, no 112-byte Object per triangle */
 void  Mesh_Set_Material(Mesh* mesh, Material* material);
 void  Mesh_Set_Origin(Mesh* mesh, point3 origin);
 void  Mesh_Set_Scale(Mesh* mesh, float scale);

@@ -17,10 +17,15 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
+#include <new>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #define RT_EPSILON 0.0001f // src/common/config.h:15
@@ -716,15 +721,15 @@ static size_t BuildNode(KDBuild& b, const std::vector<uint32_t>& vect, BoundingB
 }
 
 // what KDTree_New prepares before the recursion: depth bound, primitive boxes, world box (kdtree.c:405-435)
-static KDTree* KDTree_Inputs(Object* objs, size_t len, std::vector<BoundingBox>& boxes)
+// `boxes` = CreateKDBBs (kdtree.c:385-403), filled by the caller: from Objects for the reference-named entry
+// points, straight from the scene's triangle pool for Scene_Prepare
+static KDTree* KDTree_Inputs(const std::vector<BoundingBox>& boxes)
 {
+    const size_t len   = boxes.size();
     KDTree* tree       = new KDTree();
     tree->failed       = false;
     tree->depthReached = 0;
     tree->maxDepth     = (size_t)(8.0 + 1.8 * log2((double)len));
-
-    boxes.resize(len); // CreateKDBBs, kdtree.c:385-403
-    for (size_t i = 0; i < len; i++) boxes[i] = Surface_BoundingBox(&objs[i].surface);
 
     BoundingBox world = boxes[0]; // BoxBoundingAll, kdtree.c:207-230
     for (size_t i = 1; i < len; i++) {
@@ -737,15 +742,17 @@ static KDTree* KDTree_Inputs(Object* objs, size_t len, std::vector<BoundingBox>&
     return tree;
 }
 
-extern "C" KDTree* KDTree_New_External(Object* objs, size_t len, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
+static void Object_Boxes(Object* objs, size_t len, std::vector<BoundingBox>& boxes)
 {
-    if (!objs || len == 0 || !build || !release) {
-        set_err("KDTree_New_External: no objects or no builder");
-        return NULL;
-    }
-    std::vector<BoundingBox> boxes;
-    KDTree*                  tree = KDTree_Inputs(objs, len, boxes);
-    std::vector<float>       flat(6 * len);
+    boxes.resize(len);
+    for (size_t i = 0; i < len; i++) boxes[i] = Surface_BoundingBox(&objs[i].surface);
+}
+
+static KDTree* kd_from_boxes_external(const std::vector<BoundingBox>& boxes, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
+{
+    const size_t       len  = boxes.size();
+    KDTree*            tree = KDTree_Inputs(boxes);
+    std::vector<float> flat(6 * len);
     for (size_t i = 0; i < len; i++) {
         for (int a = 0; a < 3; a++) flat[6 * i + a] = elem(boxes[i].min, a), flat[6 * i + 3 + a] = elem(boxes[i].max, a);
     }
@@ -769,15 +776,22 @@ extern "C" KDTree* KDTree_New_External(Object* objs, size_t len, KDExternalBuild
     return tree;
 }
 
-extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
+extern "C" KDTree* KDTree_New_External(Object* objs, size_t len, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
 {
-    if (!objs || len == 0) {
-        set_err("KDTree_New: no objects");
+    if (!objs || len == 0 || !build || !release) {
+        set_err("KDTree_New_External: no objects or no builder");
         return NULL;
     }
     std::vector<BoundingBox> boxes;
-    KDTree*                  tree  = KDTree_Inputs(objs, len, boxes);
-    const BoundingBox        world = tree->worldBox;
+    Object_Boxes(objs, len, boxes);
+    return kd_from_boxes_external(boxes, build, release, device, ms_device);
+}
+
+static KDTree* kd_from_boxes_host(std::vector<BoundingBox>& boxes) // kdtree.c:405-444 after CreateKDBBs
+{
+    const size_t      len   = boxes.size();
+    KDTree*           tree  = KDTree_Inputs(boxes);
+    const BoundingBox world = tree->worldBox;
 
     std::vector<uint32_t> all(len);
     for (size_t i = 0; i < len; i++) all[i] = (uint32_t)i;
@@ -789,6 +803,17 @@ extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
         return NULL;
     }
     return tree;
+}
+
+extern "C" KDTree* KDTree_New(Object* objs, size_t len) // kdtree.c:405-444
+{
+    if (!objs || len == 0) {
+        set_err("KDTree_New: no objects");
+        return NULL;
+    }
+    std::vector<BoundingBox> boxes;
+    Object_Boxes(objs, len, boxes);
+    return kd_from_boxes_host(boxes);
 }
 
 extern "C" void KDTree_Delete(KDTree* tree) { delete tree; }
@@ -827,10 +852,56 @@ extern "C" void KDTree_Stats(const KDTree* tree, KDTreeStats* out)
 // ---------------------------------------------------------------------------------------------
 // scene (src/world/scene.c)
 // ---------------------------------------------------------------------------------------------
+// The reference keeps three vectors of 112-byte Objects (all, bounded, unbounded: scene.c:16-22, 145-166), i.e.
+// 224 bytes and two copies per triangle before anything is flattened.  Here a triangle goes from the importer's
+// Triangle straight into one compact pool (96-byte Triangle + its material), spheres and planes — a handful —
+// stay Objects, and `order` remembers the order of the Scene_Add_Object calls; Scene_Prepare derives the
+// reference's kdObjects / unboundObjs sequences from it as index lists.  The kdObjects index
+// of a primitive — the prim_id reported across the C ABI — is its position in `kdSeq`, as in the reference.
+#define SCENE_OTHER 0x80000000u
+
+// body(lo, hi) over [0, n) in contiguous ranges on the host's cores (RTX_HOST_THREADS, default up to 16); small n
+// runs on the caller.  Used where a scene build touches every triangle once: results do not depend on the split.
+static unsigned host_threads()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (n > 16) n = 16;
+    if (const char* env = getenv("RTX_HOST_THREADS")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= 64) n = (unsigned)v;
+    }
+    return n;
+}
+template <class F> static void parallel_ranges(size_t n, F&& body)
+{
+    const unsigned T = n < (1u << 16) ? 1 : host_threads();
+    if (T == 1) {
+        body((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < T; k++) th.emplace_back([&, k] { body(n * k / T, n * (k + 1) / T); });
+    body((size_t)0, n / T);
+    for (auto& t : th) t.join();
+}
+// vector whose resize() leaves new elements uninitialised: the triangle pools are resized and then filled by
+// several threads, and a value-initialising resize would first zero 100 MB on one
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<Triangle, NoInitAlloc<Triangle>> TriangleVec;
+
 struct Scene {
-    Skybox*             skybox;
-    std::vector<Object> objects, unboundObjs, kdObjects;
-    KDTree*             kdTree;
+    Skybox*                skybox;
+    TriangleVec            tris;
+    std::vector<Material*> triMat;
+    std::vector<Object>    others;           // spheres and planes
+    std::vector<uint32_t>  order;            // per added object: index into tris, or SCENE_OTHER | index into others
+    std::vector<uint32_t>  kdSeq, unboundSeq; // after Scene_Prepare: entries of `order` / indices into others
+    KDTree*                kdTree;
 };
 
 extern "C" Scene* Scene_New(Skybox* skybox)
@@ -850,45 +921,73 @@ extern "C" void Scene_Delete(Scene* scene)
 
 extern "C" bool Scene_Add_Object(Scene* scene, Object* obj)
 {
-    scene->objects.push_back(*obj);
+    if (scene->order.size() >= 0x7FFFFFFFu) {
+        set_err("Scene_Add_Object: more than 2^31 objects");
+        return false;
+    }
+    if (obj->surface.type == SURFACE_TRIANGLE) {
+        scene->order.push_back((uint32_t)scene->tris.size());
+        scene->tris.push_back(obj->surface.triangle);
+        scene->triMat.push_back(obj->material);
+    } else {
+        scene->order.push_back(SCENE_OTHER | (uint32_t)scene->others.size());
+        scene->others.push_back(*obj);
+    }
     return true;
+}
+
+// scene.c:145-166 up to the tree: the bounded / unbounded split and CreateKDBBs
+static void Scene_Split(Scene* scene, std::vector<BoundingBox>& boxes)
+{
+    scene->kdSeq.clear();
+    scene->unboundSeq.clear();
+    if (scene->kdTree) KDTree_Delete(scene->kdTree);
+    scene->kdTree = NULL;
+    scene->kdSeq.reserve(scene->order.size());
+    for (uint32_t e : scene->order) {
+        if (!(e & SCENE_OTHER) || Surface_Bounded(&scene->others[e & ~SCENE_OTHER].surface)) {
+            scene->kdSeq.push_back(e);
+        } else {
+            scene->unboundSeq.push_back(e & ~SCENE_OTHER);
+        }
+    }
+    boxes.resize(scene->kdSeq.size());
+    parallel_ranges(boxes.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const uint32_t e = scene->kdSeq[i];
+            boxes[i]         = (e & SCENE_OTHER) ? Surface_BoundingBox(&scene->others[e & ~SCENE_OTHER].surface) : Triangle_BoundingBox(&scene->tris[e]);
+        }
+    });
 }
 
 extern "C" bool Scene_Prepare(Scene* scene) // scene.c:145-166
 {
-    scene->kdObjects.reserve(scene->objects.size());
-    for (size_t i = 0; i < scene->objects.size(); i++) {
-        if (Surface_Bounded(&scene->objects[i].surface)) {
-            scene->kdObjects.push_back(scene->objects[i]);
-        } else {
-            scene->unboundObjs.push_back(scene->objects[i]);
-        }
-    }
-    if (!scene->kdObjects.empty()) {
-        scene->kdTree = KDTree_New(scene->kdObjects.data(), scene->kdObjects.size());
+    std::vector<BoundingBox> boxes;
+    Scene_Split(scene, boxes);
+    if (!boxes.empty()) {
+        scene->kdTree = kd_from_boxes_host(boxes);
         if (!scene->kdTree) return false;
-    } else {
-        scene->kdTree = NULL;
     }
     return true;
 }
 
 extern "C" bool Scene_Prepare_External(Scene* scene, KDExternalBuild build, KDExternalFree release, int device, double* ms_device)
 {
-    scene->kdObjects.reserve(scene->objects.size());
-    for (size_t i = 0; i < scene->objects.size(); i++) {
-        (Surface_Bounded(&scene->objects[i].surface) ? scene->kdObjects : scene->unboundObjs).push_back(scene->objects[i]);
+    if (!build || !release) {
+        set_err("Scene_Prepare_External: no builder");
+        return false;
     }
-    scene->kdTree = NULL;
+    std::vector<BoundingBox> boxes;
+    Scene_Split(scene, boxes);
     if (ms_device) *ms_device = 0.0;
-    if (!scene->kdObjects.empty()) {
-        scene->kdTree = KDTree_New_External(scene->kdObjects.data(), scene->kdObjects.size(), build, release, device, ms_device);
+    if (!boxes.empty()) {
+        scene->kdTree = kd_from_boxes_external(boxes, build, release, device, ms_device);
         if (!scene->kdTree) return false;
     }
     return true;
 }
 
-extern "C" size_t        Scene_Object_Count(const Scene* scene) { return scene->objects.size(); }
+extern "C" size_t        Scene_Object_Count(const Scene* scene) { return scene->order.size(); }
 extern "C" const KDTree* Scene_KDTree(const Scene* scene) { return scene->kdTree; }
 
 // ---------------------------------------------------------------------------------------------
@@ -898,7 +997,7 @@ struct Mesh {
     point3                origin;
     float                 scale;
     Material*             material;
-    std::vector<Triangle> polys;
+    TriangleVec           polys;
 };
 
 extern "C" Mesh* Mesh_New(void)
@@ -919,18 +1018,28 @@ extern "C" const Triangle* Mesh_Triangles(const Mesh* mesh) { return mesh->polys
 
 extern "C" void Mesh_AddToScene(Mesh* mesh, Scene* scene) // mesh.c:67-84
 {
-    Object obj;
-    memset(&obj, 0, sizeof obj);
-    for (size_t ii = 0; ii < mesh->polys.size(); ii++) {
-        Triangle tri = mesh->polys[ii];
-        for (int jj = 0; jj < 3; jj++) {
-            tri.vtx[jj].pos = vadd(vmuls(tri.vtx[jj].pos, mesh->scale), mesh->origin);
-        }
-        obj.material         = mesh->material;
-        obj.surface.type     = SURFACE_TRIANGLE;
-        obj.surface.triangle = tri;
-        Scene_Add_Object(scene, &obj);
+    // same transform, pos*scale + origin (mesh.c:74-76), written straight into the scene's triangle pool: no
+    // 112-byte Object is built per triangle
+    const size_t n    = mesh->polys.size();
+    const size_t base = scene->tris.size();
+    if (scene->order.size() + n >= 0x7FFFFFFFu) {
+        set_err("Mesh_AddToScene: more than 2^31 objects");
+        return;
     }
+    scene->tris.resize(base + n);
+    scene->triMat.resize(base + n, mesh->material);
+    scene->order.resize(scene->order.size() + n);
+    uint32_t* ord = scene->order.data() + scene->order.size() - n;
+    parallel_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t ii = lo; ii < hi; ii++) {
+            Triangle tri = mesh->polys[ii];
+            for (int jj = 0; jj < 3; jj++) {
+                tri.vtx[jj].pos = vadd(vmuls(tri.vtx[jj].pos, mesh->scale), mesh->origin);
+            }
+            scene->tris[base + ii] = tri;
+            ord[ii]                = (uint32_t)(base + ii);
+        }
+    });
 }
 
 // Fast paths of the importer.  The reference parses every line with up to three sscanf calls and every face
@@ -1051,36 +1160,121 @@ static bool fast_corner(const char* t, ssize_t* vi, ssize_t* vt, ssize_t* vn) //
     return true;
 }
 
+// The importer's two loop bodies (mesh.c:104-127 and :129-243), one fgets chunk at a time, shared by the FILE*
+// entry point (sequential, real fgets) and the path entry point (the file in memory, chunks parsed by several
+// threads).  Errors come back as text: the workers are not the thread whose last-error slot the caller reads.
+struct ObjVerts {
+    std::vector<point3> v, vn;
+    std::vector<point2> vt;
+};
+
+static void obj_vertex_chunk(const char* lineBuffer, ObjVerts& out) // first pass: v / vt / vn
+{
+    point3 vn, v;
+    point2 vt;
+    float  fv[3];
+    if (lineBuffer[0] != 'v') {
+        // none of the three patterns can match a line that does not start with 'v'
+    } else if (is_blank(lineBuffer[1]) && fast_floats(lineBuffer + 1, 3, fv)) {
+        out.v.push_back(point3{fv[0], fv[1], fv[2]});
+    } else if (lineBuffer[1] == 'n' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 3, fv)) {
+        out.vn.push_back(point3{fv[0], fv[1], fv[2]});
+    } else if (lineBuffer[1] == 't' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 2, fv)) {
+        out.vt.push_back(point2{fv[0], fv[1]});
+    } else if (sscanf(lineBuffer, "v %f %f %f\n", &v.x, &v.y, &v.z) == 3) {
+        out.v.push_back(v);
+    } else if (sscanf(lineBuffer, "vt %f %f\n", &vt.x, &vt.y) == 2) {
+        out.vt.push_back(vt);
+    } else if (sscanf(lineBuffer, "vn %f %f %f\n", &vn.x, &vn.y, &vn.z) == 3) {
+        out.vn.push_back(vn);
+    }
+}
+
+static std::string fmt_err(const char* fmt, const char* arg = "")
+{
+    char b[600];
+    snprintf(b, sizeof b, fmt, arg);
+    return b;
+}
+
+// second pass: one chunk that starts with "f " (the caller checked); the chunk is chopped by strtok like the
+// reference's line buffer.  false + *err on what the reference ABORTs or overruns on.
+static bool obj_face_chunk(char* lineBuffer, const ObjVerts& g, TriangleVec& polys, std::string* err)
+{
+    const std::vector<point3>&vertices = g.v, &vertexNormals = g.vn;
+    const std::vector<point2>& texCoords = g.vt;
+
+    ssize_t vi[4] = {-1, -1, -1, -1}, vn[4] = {-1, -1, -1, -1}, vt[4] = {-1, -1, -1, -1};
+    size_t  tc;
+    char*   save  = NULL; // strtok_r: same tokens as strtok, usable from several threads
+    char*   token = strtok_r(lineBuffer, " ", &save);
+    token         = strtok_r(NULL, " ", &save);
+    for (tc = 0; token != NULL; tc++) {
+        if (tc >= 4) {
+            *err = fmt_err("Mesh_Import_OBJ: face with more than 4 vertices (the reference overruns vi[4], mesh.c:136)");
+            return false;
+        }
+        if (fast_corner(token, &vi[tc], &vt[tc], &vn[tc])) {
+        } else if (sscanf(token, "%zu/%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc], (size_t*)&vn[tc]) == 3) {
+        } else if (sscanf(token, "%zu//%zu", (size_t*)&vi[tc], (size_t*)&vn[tc]) == 2) {
+        } else if (sscanf(token, "%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc]) == 2) {
+        } else if (sscanf(token, "%zu", (size_t*)&vi[tc]) == 1) {
+        } else {
+            *err = fmt_err("Mesh_Import_OBJ: no match for token \"%s\" (the reference ABORTs, mesh.c:155)", token);
+            return false;
+        }
+        token = strtok_r(NULL, " ", &save);
+    }
+
+    auto corner_ok = [&](size_t c) {
+        return vi[c] >= 1 && (size_t)vi[c] <= vertices.size() && (vn[c] < 0 || (vn[c] >= 1 && (size_t)vn[c] <= vertexNormals.size()))
+               && (vt[c] < 0 || (vt[c] >= 1 && (size_t)vt[c] <= texCoords.size()));
+    };
+    for (size_t c = 0; c < tc; c++) {
+        if (!corner_ok(c)) {
+            *err = fmt_err("Mesh_Import_OBJ: face index out of range");
+            return false;
+        }
+    }
+
+    if (tc == 4) { // quad → (0,1,2),(0,2,3); default normal NOT normalised (mesh.c:179-181)
+        static const size_t indices[2][3] = {{0, 1, 2}, {0, 2, 3}};
+        for (size_t ii = 0; ii < 2; ii++) {
+            Triangle tri;
+            for (size_t jj = 0; jj < 3; jj++) tri.vtx[jj].pos = vertices[vi[indices[ii][jj]] - 1];
+            vec3 defaultNormal = vcross(vsub(tri.vtx[1].pos, tri.vtx[0].pos), vsub(tri.vtx[2].pos, tri.vtx[0].pos));
+            for (size_t jj = 0; jj < 3; jj++) {
+                size_t index      = indices[ii][jj];
+                tri.vtx[jj].norm = vn[index] >= 0 ? vertexNormals[vn[index] - 1] : defaultNormal;
+                tri.vtx[jj].tex  = vt[index] >= 0 ? texCoords[vt[index] - 1] : point2{0.0f, 0.0f};
+            }
+            polys.push_back(tri);
+        }
+    } else if (tc == 3) { // triangle; default normal normalised (mesh.c:212-214)
+        Triangle tri;
+        for (size_t ii = 0; ii < 3; ii++) tri.vtx[ii].pos = vertices[vi[ii] - 1];
+        vec3 defaultNormal = vnorm(vcross(vsub(tri.vtx[1].pos, tri.vtx[0].pos), vsub(tri.vtx[2].pos, tri.vtx[0].pos)));
+        for (size_t ii = 0; ii < 3; ii++) {
+            tri.vtx[ii].norm = vn[ii] >= 0 ? vertexNormals[vn[ii] - 1] : defaultNormal;
+            tri.vtx[ii].tex  = vt[ii] >= 0 ? texCoords[vt[ii] - 1] : point2{0.0f, 0.0f};
+        }
+        polys.push_back(tri);
+    }
+    return true;
+}
+
 extern "C" bool Mesh_Import_OBJ(Mesh* mesh, FILE* fd) // mesh.c:87-244
 {
-    char                lineBuffer[512];
-    std::vector<point3> vertices, vertexNormals;
-    std::vector<point2> texCoords;
+    char     lineBuffer[512];
+    ObjVerts g;
 
     lineBuffer[0] = 0;
     // first pass: v / vt / vn.  `while(!feof) fgets` re-examines the last line once more when the
     // file ends in a newline, exactly as the reference does (a trailing "v" line is pushed twice;
     // harmless because nothing indexes the duplicate).
     while (!feof(fd)) {
-        point3 vn, v;
-        point2 vt;
         if (!fgets(lineBuffer, sizeof lineBuffer, fd)) { /* buffer unchanged, like the reference */ }
-        float fv[3];
-        if (lineBuffer[0] == 'v' && is_blank(lineBuffer[1]) && fast_floats(lineBuffer + 1, 3, fv)) {
-            vertices.push_back(point3{fv[0], fv[1], fv[2]});
-        } else if (lineBuffer[0] == 'v' && lineBuffer[1] == 'n' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 3, fv)) {
-            vertexNormals.push_back(point3{fv[0], fv[1], fv[2]});
-        } else if (lineBuffer[0] == 'v' && lineBuffer[1] == 't' && is_blank(lineBuffer[2]) && fast_floats(lineBuffer + 2, 2, fv)) {
-            texCoords.push_back(point2{fv[0], fv[1]});
-        } else if (lineBuffer[0] != 'v') {
-            // none of the three patterns can match a line that does not start with 'v'
-        } else if (sscanf(lineBuffer, "v %f %f %f\n", &v.x, &v.y, &v.z) == 3) {
-            vertices.push_back(v);
-        } else if (sscanf(lineBuffer, "vt %f %f\n", &vt.x, &vt.y) == 2) {
-            texCoords.push_back(vt);
-        } else if (sscanf(lineBuffer, "vn %f %f %f\n", &vn.x, &vn.y, &vn.z) == 3) {
-            vertexNormals.push_back(vn);
-        }
+        obj_vertex_chunk(lineBuffer, g);
     }
 
     fseek(fd, 0, SEEK_SET);
@@ -1089,64 +1283,170 @@ extern "C" bool Mesh_Import_OBJ(Mesh* mesh, FILE* fd) // mesh.c:87-244
     while (!feof(fd)) {
         if (!fgets(lineBuffer, sizeof lineBuffer, fd)) {}
         if (strncmp(lineBuffer, "f ", 2) != 0) continue;
-
-        ssize_t vi[4] = {-1, -1, -1, -1}, vn[4] = {-1, -1, -1, -1}, vt[4] = {-1, -1, -1, -1};
-        size_t  tc;
-        char*   token = strtok(lineBuffer, " ");
-        token         = strtok(NULL, " ");
-        for (tc = 0; token != NULL; tc++) {
-            if (tc >= 4) {
-                set_err("Mesh_Import_OBJ: face with more than 4 vertices (the reference overruns vi[4], mesh.c:136)");
-                return false;
-            }
-            if (fast_corner(token, &vi[tc], &vt[tc], &vn[tc])) {
-            } else if (sscanf(token, "%zu/%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc], (size_t*)&vn[tc]) == 3) {
-            } else if (sscanf(token, "%zu//%zu", (size_t*)&vi[tc], (size_t*)&vn[tc]) == 2) {
-            } else if (sscanf(token, "%zu/%zu", (size_t*)&vi[tc], (size_t*)&vt[tc]) == 2) {
-            } else if (sscanf(token, "%zu", (size_t*)&vi[tc]) == 1) {
-            } else {
-                set_err("Mesh_Import_OBJ: no match for token \"%s\" (the reference ABORTs, mesh.c:155)", token);
-                return false;
-            }
-            token = strtok(NULL, " ");
-        }
-
-        auto corner_ok = [&](size_t c) {
-            return vi[c] >= 1 && (size_t)vi[c] <= vertices.size() && (vn[c] < 0 || (vn[c] >= 1 && (size_t)vn[c] <= vertexNormals.size()))
-                   && (vt[c] < 0 || (vt[c] >= 1 && (size_t)vt[c] <= texCoords.size()));
-        };
-        for (size_t c = 0; c < tc; c++) {
-            if (!corner_ok(c)) {
-                set_err("Mesh_Import_OBJ: face index out of range");
-                return false;
-            }
-        }
-
-        if (tc == 4) { // quad → (0,1,2),(0,2,3); default normal NOT normalised (mesh.c:179-181)
-            static const size_t indices[2][3] = {{0, 1, 2}, {0, 2, 3}};
-            for (size_t ii = 0; ii < 2; ii++) {
-                Triangle tri;
-                for (size_t jj = 0; jj < 3; jj++) tri.vtx[jj].pos = vertices[vi[indices[ii][jj]] - 1];
-                vec3 defaultNormal = vcross(vsub(tri.vtx[1].pos, tri.vtx[0].pos), vsub(tri.vtx[2].pos, tri.vtx[0].pos));
-                for (size_t jj = 0; jj < 3; jj++) {
-                    size_t index      = indices[ii][jj];
-                    tri.vtx[jj].norm = vn[index] >= 0 ? vertexNormals[vn[index] - 1] : defaultNormal;
-                    tri.vtx[jj].tex  = vt[index] >= 0 ? texCoords[vt[index] - 1] : point2{0.0f, 0.0f};
-                }
-                mesh->polys.push_back(tri);
-            }
-        } else if (tc == 3) { // triangle; default normal normalised (mesh.c:212-214)
-            Triangle tri;
-            for (size_t ii = 0; ii < 3; ii++) tri.vtx[ii].pos = vertices[vi[ii] - 1];
-            vec3 defaultNormal = vnorm(vcross(vsub(tri.vtx[1].pos, tri.vtx[0].pos), vsub(tri.vtx[2].pos, tri.vtx[0].pos)));
-            for (size_t ii = 0; ii < 3; ii++) {
-                tri.vtx[ii].norm = vn[ii] >= 0 ? vertexNormals[vn[ii] - 1] : defaultNormal;
-                tri.vtx[ii].tex  = vt[ii] >= 0 ? texCoords[vt[ii] - 1] : point2{0.0f, 0.0f};
-            }
-            mesh->polys.push_back(tri);
+        std::string err;
+        if (!obj_face_chunk(lineBuffer, g, mesh->polys, &err)) {
+            set_err("%s", err.c_str());
+            return false;
         }
     }
     return true;
+}
+
+// fgets(buf, 512, fd) on a file held in memory: up to 511 bytes, through the first '\n'.  The caller has checked
+// p < end.  *eof is what feof() would say afterwards: set only when the read ran into the end of the file (not
+// when it stopped at a newline or on a full buffer that happens to be the file's last byte).
+static const char* mem_fgets(char* buf, const char* p, const char* end, bool* eof)
+{
+    size_t room = 511, n = 0;
+    while (n < room && p + n < end) {
+        const char c = p[n];
+        buf[n++]     = c;
+        if (c == '\n') {
+            buf[n] = 0;
+            *eof   = false;
+            return p + n;
+        }
+    }
+    buf[n] = 0;
+    *eof   = n < room; // stopped because the file ended, not because the buffer was full
+    return p + n;
+}
+
+static unsigned import_threads(size_t bytes)
+{
+    // a small file is parsed before the threads would have started (unless the caller insists)
+    return (bytes < (1u << 20) && !getenv("RTX_HOST_THREADS")) ? 1 : host_threads();
+}
+
+// The importer over a file in memory, by several threads (on a 1.1 M-triangle file parsing is
+// what is left of the scene build once the kd-tree is built on the device).  The file is cut at physical line
+// starts, so every thread sees the fgets chunks the sequential loop would see (a line longer than 511 bytes is
+// several chunks, each examined as a line of its own — also here); vertices and triangles are concatenated in
+// file order; the one chunk the reference's `while(!feof)` loop examines twice — the last, when the file does not
+// end inside it — is examined twice here too.  Result and error behaviour are those of Mesh_Import_OBJ
+// (`tests/test_host_build.py` compares the two on every asset and on the loader's corner cases).
+static bool import_obj_memory(Mesh* mesh, const char* data, size_t size)
+{
+    // more blocks than threads, handed out on demand: an OBJ file is all vertices, then all faces, so equal byte
+    // ranges are very unequal work in either pass
+    const unsigned      T = import_threads(size);
+    const unsigned      B = T == 1 ? 1 : T * 8;
+    std::vector<size_t> cut(B + 1, size);
+    cut[0] = 0;
+    for (unsigned k = 1; k < B; k++) {
+        size_t      at = std::max(cut[k - 1], size / B * k);
+        const void* nl = at < size ? memchr(data + at, '\n', size - at) : NULL;
+        cut[k]         = nl ? (size_t)((const char*)nl - data) + 1 : size;
+    }
+    struct Part {
+        ObjVerts              verts;
+        std::vector<size_t>   faces; // offsets of the chunks that start with "f "
+        TriangleVec           polys;
+        std::string           err;
+        bool                  ok = true;
+    };
+    std::vector<Part> part(B);
+    char              lastChunk[512];
+    bool              lastEof = true; // feof() after the chunk that reaches the end of the file
+    lastChunk[0]              = 0;
+
+    auto run = [&](auto&& body) { // body(block) for every block, T threads
+        std::atomic<unsigned>    next(0);
+        auto                     worker = [&] { for (unsigned b; (b = next.fetch_add(1)) < B;) body(b); };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < T; k++) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    };
+    const bool   timing = getenv("RTX_HOST_TIMING") != NULL;
+    auto         now    = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    const double t0     = now();
+
+    run([&](unsigned k) { // first pass
+        char        buf[512];
+        const char *p = data + cut[k], *end = data + cut[k + 1];
+        bool        eof = false;
+        Part&       me  = part[k];
+        while (p < end) {
+            const char* at = p;
+            p              = mem_fgets(buf, p, data + size, &eof);
+            obj_vertex_chunk(buf, me.verts);
+            if (buf[0] == 'f' && buf[1] == ' ') me.faces.push_back((size_t)(at - data));
+            if (p >= data + size) { // only the block that owns the end of the file gets here
+                memcpy(lastChunk, buf, sizeof buf);
+                lastEof = eof;
+            }
+        }
+    });
+
+    const double        t1 = now();
+    ObjVerts            g;
+    std::vector<size_t> faces;
+    {
+        size_t nv = 0, nn = 0, nt = 0, nf = 0;
+        for (auto& q : part) nv += q.verts.v.size(), nn += q.verts.vn.size(), nt += q.verts.vt.size(), nf += q.faces.size();
+        g.v.reserve(nv + 1), g.vn.reserve(nn + 1), g.vt.reserve(nt + 1), faces.reserve(nf);
+        for (auto& q : part) {
+            g.v.insert(g.v.end(), q.verts.v.begin(), q.verts.v.end());
+            g.vn.insert(g.vn.end(), q.verts.vn.begin(), q.verts.vn.end());
+            g.vt.insert(g.vt.end(), q.verts.vt.begin(), q.verts.vt.end());
+            faces.insert(faces.end(), q.faces.begin(), q.faces.end());
+            q.verts = ObjVerts();
+            std::vector<size_t>().swap(q.faces);
+        }
+    }
+    if (size > 0 && !lastEof) obj_vertex_chunk(lastChunk, g); // the loop's extra turn: fgets fails, the buffer is examined again
+    // (in the second pass that extra turn sees a face line already chopped to "f\0…" by strtok, or a line that
+    // is no face: nothing happens)
+
+    const double t2 = now();
+    run([&](unsigned k) { // second pass: the face chunks, in file order, in B equal runs
+        char         buf[512];
+        bool         eof = false;
+        Part&        me  = part[k];
+        const size_t lo = faces.size() * k / B, hi = faces.size() * (k + 1) / B;
+        me.polys.reserve((hi - lo) + (hi - lo) / 8);
+        for (size_t i = lo; i < hi; i++) {
+            mem_fgets(buf, data + faces[i], data + size, &eof);
+            if (!obj_face_chunk(buf, g, me.polys, &me.err)) {
+                me.ok = false;
+                return;
+            }
+        }
+    });
+
+    const double t3 = now();
+    // triangles in file order, up to and including the run that failed (what the sequential loop leaves behind)
+    std::vector<size_t> base(B + 1, mesh->polys.size());
+    unsigned            used = 0;
+    for (unsigned k = 0; k < B; k++) {
+        base[k + 1] = base[k] + part[k].polys.size();
+        used        = k + 1;
+        if (!part[k].ok) break;
+    }
+    if (B == 1 && mesh->polys.empty()) {
+        mesh->polys.swap(part[0].polys);
+    } else {
+        mesh->polys.resize(base[used]);
+        run([&](unsigned k) {
+            if (k < used && !part[k].polys.empty()) memcpy(&mesh->polys[base[k]], part[k].polys.data(), part[k].polys.size() * sizeof(Triangle));
+        });
+    }
+    if (timing) fprintf(stderr, "import_obj_memory: %u threads, vertices %.3f s, concat %.3f s, faces %.3f s, triangles %.3f s\n", T, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    if (!part[used - 1].ok) {
+        set_err("%s", part[used - 1].err.c_str());
+        return false;
+    }
+    return true;
+}
+
+extern "C" bool Mesh_Import_OBJ_Memory(Mesh* mesh, const char* data, size_t size)
+{
+    if (!mesh || (!data && size)) {
+        set_err("Mesh_Import_OBJ_Memory: null argument");
+        return false;
+    }
+    return import_obj_memory(mesh, data, size);
 }
 
 extern "C" bool Mesh_Import_OBJ_Path(Mesh* mesh, const char* path)
@@ -1156,9 +1456,27 @@ extern "C" bool Mesh_Import_OBJ_Path(Mesh* mesh, const char* path)
         set_err("cannot open %s", path);
         return false;
     }
-    bool ok = Mesh_Import_OBJ(mesh, fd);
+    std::vector<char> data;
+    size_t            have = 0, got;
+    if (fseek(fd, 0, SEEK_END) == 0) {
+        const long n = ftell(fd);
+        if (n > 0) data.resize((size_t)n);
+        fseek(fd, 0, SEEK_SET);
+    }
+    for (;;) { // the size is a hint: read until fread says there is no more
+        if (have == data.size()) data.resize(have + (1u << 16));
+        got = fread(data.data() + have, 1, data.size() - have, fd);
+        if (got == 0) break;
+        have += got;
+    }
+    data.resize(have);
+    const bool bad = ferror(fd) != 0;
     fclose(fd);
-    return ok;
+    if (bad) {
+        set_err("cannot read %s", path);
+        return false;
+    }
+    return import_obj_memory(mesh, data.data(), data.size());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1279,9 +1597,9 @@ extern "C" SceneFlat* Scene_Flatten(Scene* scene)
     };
 
     // bounded primitives, in kdObjects order
-    const size_t nk = scene->kdObjects.size();
+    const size_t nk = scene->kdSeq.size();
     size_t       T = 0, S = 0;
-    for (size_t i = 0; i < nk; i++) (scene->kdObjects[i].surface.type == SURFACE_TRIANGLE ? T : S)++;
+    for (size_t i = 0; i < nk; i++) ((scene->kdSeq[i] & SCENE_OTHER) ? S : T)++;
     std::vector<uint32_t> kd2ref(nk);
     f->tri_pos.resize(9 * T);
     f->tri_nrm.resize(9 * T);
@@ -1291,26 +1609,22 @@ extern "C" SceneFlat* Scene_Flatten(Scene* scene)
     f->sph.resize(4 * S);
     f->sph_mat.resize(S);
     f->sph_obj.resize(S);
-    size_t ti = 0, si = 0;
+    // slots and materials in kdObjects order (cheap, sequential: the order materials are first met fixes their
+    // indices), then the transposition of the triangle pool into the SoA planes on all cores
+    size_t          ti = 0, si = 0;
+    const Material* lastMat = NULL;
+    uint8_t         lastId  = 0;
     for (size_t i = 0; i < nk; i++) {
-        const Object& o = scene->kdObjects[i];
-        if (o.surface.type == SURFACE_TRIANGLE) {
-            const Triangle& tr = o.surface.triangle;
-            for (int v = 0; v < 3; v++) {
-                f->tri_pos[(3 * v + 0) * T + ti] = tr.vtx[v].pos.x;
-                f->tri_pos[(3 * v + 1) * T + ti] = tr.vtx[v].pos.y;
-                f->tri_pos[(3 * v + 2) * T + ti] = tr.vtx[v].pos.z;
-                f->tri_nrm[(3 * v + 0) * T + ti] = tr.vtx[v].norm.x;
-                f->tri_nrm[(3 * v + 1) * T + ti] = tr.vtx[v].norm.y;
-                f->tri_nrm[(3 * v + 2) * T + ti] = tr.vtx[v].norm.z;
-                f->tri_uv[(2 * v + 0) * T + ti]  = tr.vtx[v].tex.x;
-                f->tri_uv[(2 * v + 1) * T + ti]  = tr.vtx[v].tex.y;
-            }
-            f->tri_mat[ti] = intern_mat(o.material);
+        const uint32_t e = scene->kdSeq[i];
+        if (!(e & SCENE_OTHER)) {
+            const Material* m = scene->triMat[e];
+            if (m != lastMat || !m) lastId = intern_mat(m), lastMat = m;
+            f->tri_mat[ti] = lastId;
             f->tri_obj[ti] = (uint32_t)i;
             kd2ref[i]      = (uint32_t)ti;
             ti++;
         } else {
+            const Object& o = scene->others[e & ~SCENE_OTHER];
             f->sph[0 * S + si] = o.surface.sphere.c.x;
             f->sph[1 * S + si] = o.surface.sphere.c.y;
             f->sph[2 * S + si] = o.surface.sphere.c.z;
@@ -1321,11 +1635,26 @@ extern "C" SceneFlat* Scene_Flatten(Scene* scene)
             si++;
         }
     }
-    const size_t P = scene->unboundObjs.size();
+    parallel_ranges(T, [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            const Triangle& tr = scene->tris[scene->kdSeq[f->tri_obj[t]]];
+            for (int v = 0; v < 3; v++) {
+                f->tri_pos[(3 * v + 0) * T + t] = tr.vtx[v].pos.x;
+                f->tri_pos[(3 * v + 1) * T + t] = tr.vtx[v].pos.y;
+                f->tri_pos[(3 * v + 2) * T + t] = tr.vtx[v].pos.z;
+                f->tri_nrm[(3 * v + 0) * T + t] = tr.vtx[v].norm.x;
+                f->tri_nrm[(3 * v + 1) * T + t] = tr.vtx[v].norm.y;
+                f->tri_nrm[(3 * v + 2) * T + t] = tr.vtx[v].norm.z;
+                f->tri_uv[(2 * v + 0) * T + t]  = tr.vtx[v].tex.x;
+                f->tri_uv[(2 * v + 1) * T + t]  = tr.vtx[v].tex.y;
+            }
+        }
+    });
+    const size_t P = scene->unboundSeq.size();
     f->plane.resize(6 * P);
     f->plane_mat.resize(P);
     for (size_t i = 0; i < P; i++) {
-        const Object& o      = scene->unboundObjs[i];
+        const Object& o      = scene->others[scene->unboundSeq[i]];
         f->plane[0 * P + i] = o.surface.plane.normal.x;
         f->plane[1 * P + i] = o.surface.plane.normal.y;
         f->plane[2 * P + i] = o.surface.plane.normal.z;

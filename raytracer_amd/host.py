@@ -229,6 +229,8 @@ def lib() -> C.CDLL:
     sig("Mesh_New", vp)
     sig("Mesh_Delete", None, vp)
     sig("Mesh_Import_OBJ_Path", C.c_bool, vp, C.c_char_p)
+    sig("Mesh_Import_OBJ", C.c_bool, vp, vp)
+    sig("Mesh_Import_OBJ_Memory", C.c_bool, vp, C.c_char_p, C.c_size_t)
     sig("Mesh_AddToScene", None, vp, vp)
     sig("Mesh_Set_Material", None, vp, C.POINTER(Material))
     sig("Mesh_Set_Origin", None, vp, point3)

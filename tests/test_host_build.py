@@ -159,6 +159,88 @@ def test_obj_import_fast_float_path_is_strtof(tmp_path):
     assert got[0].shape[0] == len(range(0, len(txt) - 2, 3)) and np.array_equal(got[0], got[1])
 
 
+def _import_bits(L, importer):
+    m = L.Mesh_New()
+    ok = importer(m)
+    n = L.Mesh_Triangle_Count(m)
+    a = np.ctypeslib.as_array(C.cast(L.Mesh_Triangles(m), C.POINTER(C.c_uint32)), (n, 24)).copy() if n else np.zeros((0, 24), np.uint32)
+    L.Mesh_Delete(m)
+    return bool(ok), a, (host.last_error() if not ok else "")
+
+
+def _import_file(L, path):
+    """The sequential importer on a FILE*, as the reference calls it (mesh.c:87)."""
+    libc = C.CDLL(None)
+    libc.fopen.restype, libc.fopen.argtypes = C.c_void_p, [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+
+    def run(m):
+        fd = libc.fopen(str(path).encode(), b"r")
+        assert fd
+        try:
+            return L.Mesh_Import_OBJ(m, fd)
+        finally:
+            libc.fclose(fd)
+    return _import_bits(L, run)
+
+
+def test_obj_import_threaded_equals_sequential(tmp_path, monkeypatch):
+    """Mesh_Import_OBJ_Path / _Memory parse the file in memory with several threads; Mesh_Import_OBJ is the
+    reference's sequential fgets loop.  Same triangles in the same order, same success and the same message on
+    failure — on the assets and on the loader's corner cases: lines longer than the 512-byte buffer (examined as
+    several lines), no newline at the end, a last line exactly filling the buffer, a trailing vertex line (pushed
+    twice by `while(!feof)`, mesh.c:100), CRLF, empty files, errors early and late in the file."""
+    L = host.lib()
+    rng = np.random.default_rng(23)
+    nv = 4000
+    v = rng.normal(size=(nv, 3)).astype(np.float32)
+    body = "".join("v %.9g %.9g %.9g\n" % tuple(x) for x in v) + "".join("vn %.9g %.9g %.9g\n" % tuple(x) for x in v[:500]) + \
+        "".join("vt %.9g %.9g\n" % tuple(x[:2]) for x in v[:300])
+    faces = ""
+    for _ in range(6000):
+        a, b, c, d = rng.integers(1, nv + 1, 4)
+        k = int(rng.integers(0, 4))
+        faces += ["f %d %d %d\n" % (a, b, c), "f %d//%d %d//%d %d//%d\n" % (a, a % 500 + 1, b, b % 500 + 1, c, c % 500 + 1),
+                  "f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a % 300 + 1, a % 500 + 1, b, b % 300 + 1, b % 500 + 1, c, c % 300 + 1, c % 500 + 1, d, d % 300 + 1, d % 500 + 1),
+                  "f %d/%d %d/%d %d/%d\n" % (a, a % 300 + 1, b, b % 300 + 1, c, c % 300 + 1)][k]
+    long_comment = "# " + "x" * 700 + " v 1 2 3\n"                      # its tail is a chunk of its own; does not start with v
+    long_vertex = "v 1 2 3" + " " * 503 + "\n"                          # 511 bytes before the newline: chunk, then "\n" alone
+    long_split = "#" + " " * 510 + "v 7 8 9\n" + "#" + " " * 510 + "f 1 2 3\n"  # a continuation chunk that IS a vertex / a face
+    cases = {
+        "plain": body + faces,
+        "no_final_newline": body + faces + "f 1 2 3",
+        "trailing_vertex": body + faces + "v 9 9 9\n",
+        "trailing_vertex_no_newline": body + faces + "v 9 9 9",
+        "long_lines": body + long_comment + long_vertex + long_split + faces + long_comment,
+        "last_line_fills_buffer": body + faces + "v 1 2 3" + " " * 504,
+        "crlf": (body + faces).replace("\n", "\r\n"),
+        "empty": "",
+        "only_newline": "\n",
+        "faces_before_vertices": faces[:2000].rsplit("\n", 1)[0] + "\n" + body,
+        "error_late": body + faces + "f 1 2 x\n" + faces[:500].rsplit("\n", 1)[0] + "\n",
+        "error_early": body + "f 1 2 3 4 5\n" + faces,
+        "error_index": body + faces + "f 1 2 %d\n" % (nv + 5),
+    }
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RTX_HOST_THREADS", threads)
+        for name, text in cases.items():
+            pth = tmp_path / (name + ".obj")
+            pth.write_bytes(text.encode())
+            want = _import_file(L, pth)
+            got = _import_bits(L, lambda m: L.Mesh_Import_OBJ_Path(m, str(pth).encode()))
+            mem = _import_bits(L, lambda m: L.Mesh_Import_OBJ_Memory(m, text.encode(), len(text.encode())))
+            for g in (got, mem):
+                assert g[0] == want[0] and g[2] == want[2], (name, threads, g[2], want[2])
+                assert g[1].shape == want[1].shape and np.array_equal(g[1], want[1]), (name, threads)
+            assert want[0] == (not name.startswith("error")) or name == "faces_before_vertices", name
+    assert _import_file(L, tmp_path / "plain.obj")[1].shape[0] > 6000
+    monkeypatch.setenv("RTX_HOST_THREADS", "5")
+    for name in ("teapot", "bunny", "pear"):
+        want = _import_file(L, assets.obj_path(name))
+        got = _import_bits(L, lambda m: L.Mesh_Import_OBJ_Path(m, assets.obj_path(name).encode()))
+        assert want[0] and got[0] and np.array_equal(got[1], want[1])
+
+
 def test_obj_import_quad_default_normal_is_not_normalised(tmp_path):
     L = host.lib()
     m = L.Mesh_New()
