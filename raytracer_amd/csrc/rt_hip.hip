@@ -92,7 +92,7 @@ struct rtx_scene {
     hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
     unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
-    unsigned persist_blocks[8]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)] (0 = not queried yet)
+    unsigned persist_blocks[10]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)], [8 + variant - 4]: tail (0 = not queried yet)
 };
 
 static int workspace(rtx_scene* sc, uint64_t bytes, char** out)
@@ -164,6 +164,13 @@ extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
     return RTX_OK;
 }
 
+#ifndef TAIL_WAVES
+#define TAIL_WAVES 4 // waves per SIMD the tail kernel is compiled for (128 VGPRs: the shading code spills 26 values)
+#endif
+#ifndef TAIL_MAX_DEFAULT
+#define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
+#endif
+#define TAIL_COUNTERS 80 // u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
 static int validate_desc(const rtx_scene_desc* d)
 {
     if (!d) return fail(RTX_E_INVALID, "null scene description");
@@ -546,7 +553,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     }
     {
         const uint64_t* c = nullptr;
-        std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64), 0); // [80 * l ..]: queue count and work counters of lane l
+        std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64) + TAIL_COUNTERS, 0); // [80 * l ..]: queue count and work counters of lane l; then the tail kernel's
         UP(upload(sc, zeros.data(), zeros.size(), &c));
         sc->d_counters = (uint64_t*)c;
     }
@@ -739,10 +746,26 @@ DEV uint64_t wave_bcast_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// TAIL variant of the closest-hit kernel (k_trace_flat<..., true>): the rest of the bounce loop in ONE launch.  A lane
+// that has found its ray's closest hit does not hand the hit to a shade pass: it waits (ST_SHADE) until enough lanes of
+// its wave wait with it, Material_Bounce runs for them in place, and a path that goes on starts its next walk at once in
+// the same lane; the lane asks the queue for a new path only when its path has ended.  The path state that only shading
+// needs (throughput, RNG state, path id) stays in the path's queue record and is updated there.  Used for queues too
+// short to fill the chip (a rank's share of a frame split over several GPUs, the deep passes of small frames), where a
+// pass per depth costs more in launch ramps and drains than in work.
+struct TailArgs {
+    float*              result;   // per-path result slots, component stride rcap
+    uint64_t            rcap;
+    uint32_t            depth0;   // ray depth of the queue's rays
+    uint32_t            max_depth;
+    unsigned long long* counts;   // [d]: rays traced at depth d beyond depth0's own; [RTX_MAX_DEPTH]: paths shaded
+    uint32_t            shade_min; // lanes that must wait before the shade block runs
+};
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                        uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
-                                                       uint32_t chunk, uint64_t* counters, uint32_t /*tune*/)
+                                                       uint32_t chunk, uint64_t* counters, uint32_t /*tune*/, TailArgs /*unused*/)
 {
     const uint32_t lane    = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -935,7 +958,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
 // predicated store), and the leaf keeps the NEXT leaf reference in flight while testing the
 // current primitive.
 // ---------------------------------------------------------------------------------------------
-enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2 };
+enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2, ST_SHADE = 3 };
 // One wave per block: the waves share nothing, and a block's LDS and wave slots come free the moment ITS wave
 // has finished its last ray — with 4-wave blocks the slowest of four decided, which kept the next kernel's
 // blocks (the other lane of rtx_render_device, or simply the shade pass) out of the CU during the tail.
@@ -992,12 +1015,12 @@ DEV uint32_t wave_scan_max(uint32_t v) // inclusive prefix maximum over the lane
 DEV float lane_read(float v, uint32_t src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)__float_as_uint(v))); }
 DEV uint32_t lane_read(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
 
-template <bool COUNT, bool CULL, bool COOP>
+template <bool COUNT, bool CULL, bool COOP, bool TAIL = false>
 // (waves_per_eu(6): the walk needs 88 VGPRs as the compiler likes it, 5 waves per SIMD; held to 80 it spills two
 // values that only the refill touches and runs 6 waves per SIMD — 95.0 -> 91.8 ms; 7 waves cost 8 spills and lose)
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? TAIL_WAVES : 6))) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
-                                                    uint32_t chunk, uint64_t* counters, uint32_t tune)
+                                                    uint32_t chunk, uint64_t* counters, uint32_t tune, TailArgs ta)
 {
     // Block scheduling (wave-uniform): the INNER and LEAF blocks cost ~60 and ~90 vector instructions whatever
     // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
@@ -1005,7 +1028,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
     const uint32_t leaf_min = tune & 0xFFu, inner_min = (tune >> 8) & 0xFFu, refill_min = (tune >> 16) & 0xFFu;
     // the root's box is tested when a ray is loaded — unless the caller knows the rays start on the scene's surfaces
     // (bounce passes), where that test never fails and the children's tests one step later do its work
-    const bool     root_test = !((tune >> 25) & 1u);
+    const bool     root_test = !TAIL && !((tune >> 25) & 1u);
     const uint32_t lane    = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -1033,6 +1056,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
 #define WWIN(i) s_win[wv + (i)]                                // keeps the compiler from moving them)
 #define WOWN(i) s_own[wv + (i)]
 #define LDS_ORDER() asm volatile("" ::: "memory")
+    __shared__ uint32_t s_tail[TAIL ? RTX_MAX_DEPTH + 64 : 1]; // TAIL: rays started per depth, [RTX_MAX_DEPTH]: paths shaded
+    uint32_t            depth = 0;                             // TAIL: ray depth of this lane's path
+    float* const        qw    = const_cast<float*>(rays);      // TAIL: the queue records are updated in place
+    if (TAIL) {
+        s_tail[lane] = 0u, s_tail[64 + lane] = 0u;
+        LDS_ORDER();
+    }
     int      sp   = 0;   // stack height
     int      base = 0;   // entries [base, sp) are in LDS, [0, base) in scratch
     uint2    stk[RTX_STACK];
@@ -1125,6 +1155,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
                     sp    = 0;
                     base  = 0;
                     state = ST_INNER;
+                    if (TAIL) depth = ta.depth0;
                     if (CULL && root_test && cullOK && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o, inv, RTX_INF)) {
                         // the ray misses the box of everything in the tree: finished here, the lane stays free
                         if (COUNT) vis.culled++;
@@ -1138,9 +1169,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
         }
 
         bool           pop = false, fin = false;
-        const uint32_t nI = (uint32_t)__popcll(__ballot(state == ST_INNER)), nL = 64u - nidle - nI;
-        const bool     doLeaf  = nL >= leaf_min || nI == 0u;
+        const uint32_t nI = (uint32_t)__popcll(__ballot(state == ST_INNER));
+        const uint32_t nS = TAIL ? (uint32_t)__popcll(__ballot(state == ST_SHADE)) : 0u;
+        const uint32_t nL = 64u - nidle - nI - nS;
+        const bool     doLeaf  = TAIL ? (nL >= leaf_min || (nI == 0u && nL != 0u)) : (nL >= leaf_min || nI == 0u);
         const bool     doInner = nI >= inner_min || !doLeaf;
+        // TAIL: shading runs for a batch of waiting lanes, or when nothing else in the wave can move
+        const bool     doShade = TAIL && nS != 0u && (nS >= ta.shade_min || (nI == 0u && nL == 0u));
         if (COUNT) { // wave statistics (wave-uniform): block executions and the lanes they served
             ws[0]++;
             if (doInner && nI) ws[1]++, ws[2] += nI;
@@ -1353,9 +1388,89 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6))
             }
         }
         if (fin) {
-            write_hit(best, bestT, bu, bv);
-            state = ST_IDLE;
+            if (TAIL) { // Scene_ClosestHit's merge with the unbounded list (as in write_hit); the hit stays in the lane
+                if (best == HIT_MISS) bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
+                if (pRef != HIT_MISS && (best == HIT_MISS || pBest < bestT)) best = pRef, bestT = pBest, bu = 0.0f, bv = 0.0f;
+                state = ST_SHADE;
+            } else {
+                write_hit(best, bestT, bu, bv);
+                state = ST_IDLE;
+            }
         }
+        if (TAIL && doShade && state == ST_SHADE) {
+            // k_shade's body for the lanes that wait: RayColor's miss / bounce / stop cases (renderer.c:54-76)
+            const uint64_t cs = stride ? stride : 1, rb = (uint64_t)ridx * (stride ? 1 : Q_RECORD);
+            f3             T   = mk3(qw[Q_TR * cs + rb], qw[Q_TG * cs + rb], qw[Q_TB * cs + rb]);
+            const uint32_t pid = __float_as_uint(qw[Q_PID * cs + rb]);
+            bool           goOn = false;
+            f3             L;
+            if (best == HIT_MISS) {
+                L = vmulc(T, Skybox_ColorAt(S, d));
+            } else {
+                Rng  rng = Rng{__float_as_uint(qw[Q_S0 * cs + rb]), __float_as_uint(qw[Q_S1 * cs + rb]), __float_as_uint(qw[Q_S2 * cs + rb]),
+                               __float_as_uint(qw[Q_S3 * cs + rb])};
+                HitD h   = make_hitinfo(S, o, d, best, bestT, bu, bv);
+                f3   surf, emit, dout;
+                const bool cont = Material_Bounce(S, S.mats[h.mat], d, h, rng, surf, emit, dout);
+                atomicAdd(&s_tail[RTX_MAX_DEPTH], 1u);
+                if (cont) {
+                    T = vmulc(T, surf);
+                    if (depth + 1u >= ta.max_depth) {
+                        L = vmulc(T, mk3(0.0f, 0.0f, 0.0f)); // depth exhausted: surface * black, NaNs included (see k_shade)
+                    } else {
+                        goOn = true;
+                        o    = h.pos;
+                        d    = vnorm(dout); // Ray_Make
+                        qw[Q_TR * cs + rb] = T.x, qw[Q_TG * cs + rb] = T.y, qw[Q_TB * cs + rb] = T.z;
+                        qw[Q_S0 * cs + rb] = __uint_as_float(rng.s0), qw[Q_S1 * cs + rb] = __uint_as_float(rng.s1);
+                        qw[Q_S2 * cs + rb] = __uint_as_float(rng.s2), qw[Q_S3 * cs + rb] = __uint_as_float(rng.s3);
+                    }
+                } else {
+                    L = vmulc(T, emit);
+                }
+            }
+            if (goOn) {
+                // the next ray of the path, in the same lane: what the refill does for a ray it loads
+                depth++;
+                atomicAdd(&s_tail[depth], 1u);
+                inv = vdivc(mk3(1.0f, 1.0f, 1.0f), d);
+                odd = vdivc(o, d);
+                if (CULL) {
+                    const float big = 3.0e38f;
+                    inv.x = fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x;
+                    inv.y = fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y;
+                    inv.z = fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z;
+                    const float rx = o.x - S.cull_c[0], ry = o.y - S.cull_c[1], rz = o.z - S.cull_c[2];
+                    const float r2 = rx * rx + ry * ry + rz * rz, d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    cullOK         = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
+                }
+                asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                pBest = RTX_INF;
+                pRef  = HIT_MISS;
+                for (uint32_t i = 0; i < S.n_planes; i++) {
+                    const float* pl = S.plane + 8ull * i;
+                    float        tp2;
+                    if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                        pBest = tp2;
+                        pRef  = HIT_PLANE | i;
+                    }
+                }
+                node  = S.root;
+                tMax  = RTX_INF;
+                sp    = 0;
+                base  = 0;
+                state = ST_INNER;
+            } else {
+                ta.result[0 * ta.rcap + pid] = L.x, ta.result[1 * ta.rcap + pid] = L.y, ta.result[2 * ta.rcap + pid] = L.z;
+                state = ST_IDLE;
+            }
+        }
+    }
+    if (TAIL) { // one wave per block: its LDS counters go out once
+        LDS_ORDER();
+        const uint32_t c0 = s_tail[lane], c1 = lane == 0 ? s_tail[RTX_MAX_DEPTH] : 0u;
+        if (c0) atomicAdd(ta.counts + lane, (unsigned long long)c0);
+        if (c1) atomicAdd(ta.counts + RTX_MAX_DEPTH, (unsigned long long)c1);
     }
     if (COUNT) {
         add_visits(counters, vis);
@@ -1745,8 +1860,18 @@ static int trace_variant()
     return v;
 }
 
+// true when launch_trace would run one of the kernels that have a TAIL variant (the cooperative ones)
+static bool tail_capable(const rtx_scene* sc, bool literal)
+{
+    const int  tv      = trace_variant();
+    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
+    const int  variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
+    return variant >= 4;
+}
+
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
-                        bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false)
+                        bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false,
+                        const TailArgs* tail = nullptr)
 {
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
@@ -1766,7 +1891,9 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     }
     // persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
     // that would not fit simply start later and find the queue empty — nothing waits on another block)
-    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t);
+    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t,
+                                  TailArgs);
+    if (tail && (variant < 4 || count)) return fail(RTX_E_INVALID, "no tail variant of this closest-hit kernel");
     static uint32_t tune = 0;
     if (tune == 0) { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes)
         unsigned    a = 16, b = 8, c = REFILL_MIN;
@@ -1781,7 +1908,8 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
                             : variant == 3 ? (count ? k_trace_flat<true, true, false> : k_trace_flat<false, true, false>)
                             : variant == 4 ? (count ? k_trace_flat<true, true, true> : k_trace_flat<false, true, true>)
                                            : (count ? k_trace_flat<true, false, true> : k_trace_flat<false, false, true>);
-    const int     slot    = (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
+    if (tail) kern = variant == 4 ? k_trace_flat<false, true, true, true> : k_trace_flat<false, false, true, true>;
+    const int     slot    = tail ? 8 + (variant - 4) : (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
     const int     bs      = variant == 1 ? 256 : TRACE_BLOCK;
     if (sc->persist_blocks[slot] == 0) {
         int per_cu = 0, cus = 0;
@@ -1801,8 +1929,11 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     uint64_t chunk = n >= (64ull << 20) ? 160 : 64;
     if (const char* e = getenv("RTX_TRACE_CHUNK")) chunk = std::max(16, atoi(e)); // experiments
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
+    TailArgs ta;
+    memset(&ta, 0, sizeof ta);
+    if (tail) ta = *tail;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
-                       tune | (bounce_rays && !count ? 1u << 25 : 0u));
+                       tune | (bounce_rays && !count ? 1u << 25 : 0u), ta);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
@@ -2003,6 +2134,16 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
 
     unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
     HIPCHECK(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint64_t), st));
+    // The tail of the bounce loop in one launch (k_trace_flat<..., TAIL>): once a lane's queue is too short to fill the
+    // chip, a pass per depth costs more in ramps and drains than in work.  RTX_TAIL_MAX = longest queue handed to it
+    // (0: never); read per call, the tests switch it.  Same paths, same results: a path's RNG state and result slot are its own.
+    unsigned long long* d_tail = (unsigned long long*)&sc->d_counters[RTX_MAX_LANES * 80];
+    const char*         tm_env   = getenv("RTX_TAIL_MAX");
+    const long long     tail_max = (count || !tail_capable(sc, literal)) ? 0 : tm_env ? atoll(tm_env) : TAIL_MAX_DEFAULT;
+    const char*         ts_env   = getenv("RTX_TAIL_SHADE_MIN");
+    const uint32_t      tail_shade_min = (uint32_t)std::min(64, std::max(1, ts_env ? atoi(ts_env) : 16));
+    bool                tail_used = false;
+    HIPCHECK(hipMemsetAsync(d_tail, 0, TAIL_COUNTERS * sizeof(uint64_t), st));
 
     int        nev = 0;
     hipEvent_t evA, evB;
@@ -2107,6 +2248,21 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         a.n   = a.last ? 0 : *a.h_alive;
         a.cur ^= 1;
         a.qin = soa(a, a.cur);
+        if (a.n > 0 && (long long)a.n <= tail_max && a.depth + 1 < p->max_depth) {
+            // all remaining depths of these paths in one launch; the kernel counts the rays it starts beyond this queue's
+            a.depth++;
+            local.rays_at_depth[a.depth] += a.n;
+            local.rays_total += a.n;
+            const TailArgs ta = {a.result, cap, a.depth, p->max_depth, d_tail, tail_shade_min};
+            int            r  = timed(1, a.depth, a.s, [&] {
+                (void)launch_trace(sc, a.qin.base, cap, a.n, a.hits.base, cap, a.s, false, sc->d_counters, literal, a.work, true, &ta);
+            });
+            if (r != RTX_OK) return r;
+            local.trace_launches++;
+            tail_used = true;
+            a.n       = 0; // nothing is left for a further pass
+            a.depth   = p->max_depth;
+        }
         if (a.bin && a.n > 0) {
             int r = timed(4, a.depth, a.s, [&] {
                 uint32_t* chunk = a.bin_cnt + (1u << BIN_BITS);
@@ -2160,6 +2316,12 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2], local.visits_culled = c[3];
     local.hits_shaded  = c[4];
     for (int i = 0; i < 8; i++) local.wave_stats[i] = c[8 + i];
+    if (tail_used) {
+        uint64_t tc[RTX_MAX_DEPTH + 1];
+        HIPCHECK(hipMemcpy(tc, d_tail, sizeof tc, hipMemcpyDeviceToHost));
+        for (int i = 0; i < RTX_MAX_DEPTH; i++) local.rays_at_depth[i] += tc[i], local.rays_total += tc[i];
+        local.hits_shaded += tc[RTX_MAX_DEPTH];
+    }
     local.samples_done = g.n_samples;
     if (stats) *stats = local;
     return RTX_OK;

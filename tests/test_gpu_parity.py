@@ -318,6 +318,7 @@ def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monke
     sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
     p = hip.make_params(480, 270, 8, 8, seed=(7, 8))
     frames = {}
+    monkeypatch.setenv("RTX_TAIL_MAX", "0")  # a pass per depth: the tail kernel would take these short queues before they are binned
     for name, env in (("forced", {"RTX_SORT_MIN": "1"}), ("off", {"RTX_SORT_DEPTH": "0"}), ("default", {})):
         for k in ("RTX_SORT_MIN", "RTX_SORT_DEPTH"):
             monkeypatch.delenv(k, raising=False)
@@ -330,14 +331,42 @@ def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,depth", [("materials", 320, 180, 8, 8), ("dragon1", 240, 135, 8, 8), ("pear", 160, 90, 4, 16), ("teapot", 200, 100, 4, 2)])
+def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeypatch, scene, w, h, spp, depth):
+    """Short queues go through the rest of the bounce loop in one launch (closest hit, shading and the next ray in
+    the same lane: k_trace_flat<..., TAIL>) instead of a pass per depth.  The same paths with the same RNG streams:
+    the frame, the rays per depth and the number of shaded hits are those of the per-depth passes, bit for bit,
+    wherever the hand-over happens and however many lanes the in-kernel shading waits for."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    p = hip.make_params(w, h, spp, depth, seed=(3, 5))
+    out = {}
+    for name, env in (("passes", {"RTX_TAIL_MAX": "0"}), ("default", {}), ("late", {"RTX_TAIL_MAX": str(w * h * spp // 3)}),
+                      ("one_lane", {"RTX_TAIL_SHADE_MIN": "1"}), ("full_wave", {"RTX_TAIL_SHADE_MIN": "64"}), ("literal", {})):
+        for k in ("RTX_TAIL_MAX", "RTX_TAIL_SHADE_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[name] = ds.render(sc.rtx_camera(), hip.make_params(w, h, spp, depth, seed=(3, 5), flags=hip.RTX_TRACE_LITERAL) if name == "literal" else p)
+    ref = out["passes"]
+    assert sum(ref[2]["rays_at_depth"][2:]) > 0 or depth <= 2
+    for name, (bgr, acc, st) in out.items():
+        assert np.array_equal(bgr, ref[0]) and same_bits(acc, ref[1]), name
+        assert st["rays_at_depth"] == ref[2]["rays_at_depth"] and st["rays_total"] == ref[2]["rays_total"], name
+        assert st["hits_shaded"] == ref[2]["hits_shaded"], name
+    assert out["default"][2]["trace_launches"] < ref[2]["trace_launches"] or depth <= 2
+
+
+@pytest.mark.gpu
 def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monkeypatch):
     """Frames whose sizes fit no tile, wave or slab boundary: one launch, tiny slabs, several lanes and a forced
     binning pass all give the same bits and trace the same rays."""
     sc, ds = built_scenes("materials"), device_scenes("materials")
     for (w, h, spp, depth) in ((3, 2, 1, 1), (33, 17, 3, 5), (257, 129, 2, 4), (5, 7, 64, 3), (64, 64, 5, 8)):
         base = None
-        for env, mpf in (({}, 0), ({}, 777), ({"RTX_OVERLAP": "3"}, 0), ({"RTX_OVERLAP": "2", "RTX_SORT_MIN": "1"}, 1500), ({"RTX_SORT_MIN": "1"}, 0)):
-            for k in ("RTX_OVERLAP", "RTX_SORT_MIN"):
+        for env, mpf in (({"RTX_TAIL_MAX": "0"}, 0), ({}, 0), ({}, 777), ({"RTX_TAIL_MAX": "0"}, 777), ({"RTX_OVERLAP": "3"}, 0),
+                         ({"RTX_OVERLAP": "2", "RTX_SORT_MIN": "1", "RTX_TAIL_MAX": "0"}, 1500), ({"RTX_SORT_MIN": "1", "RTX_TAIL_MAX": "0"}, 0),
+                         ({"RTX_OVERLAP": "1", "RTX_TAIL_MAX": "300", "RTX_TAIL_SHADE_MIN": "3"}, 1500)):
+            for k in ("RTX_OVERLAP", "RTX_SORT_MIN", "RTX_TAIL_MAX", "RTX_TAIL_SHADE_MIN"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
