@@ -168,7 +168,9 @@ typedef struct rtx_stats {
     uint64_t visits_inner, visits_leaf, visits_prim; /* only with RTX_RENDER_COUNT_VISITS */
     uint64_t hits_shaded;                            /* rays that reached Material_Bounce   */
     double   ms_total;                               /* whole call, device time (events)    */
-    double   ms_trace;                               /* sum over closest-hit launches        */
+    double   ms_trace;                               /* sum over closest-hit launches; a queue of <= 2 M rays finishes all its
+                                                      * remaining depths in ONE launch that also shades: that
+                                                      * launch counts here, at the depth it starts at (no COUNT_VISITS) */
     double   ms_shade;
     double   ms_raygen;
     double   ms_resolve;

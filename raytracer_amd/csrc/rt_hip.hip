@@ -2210,10 +2210,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         const uint32_t depth = a.depth;
         local.rays_at_depth[depth] += a.n;
         local.rays_total += a.n;
-        int r = timed(1, depth, a.s, [&] {
-            (void)launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
+        int lrc = RTX_OK;
+        int r   = timed(1, depth, a.s, [&] {
+            lrc = launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
         });
-        if (r != RTX_OK) return r;
+        if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
         local.trace_launches++;
         HIPCHECK(hipMemsetAsync(a.d_cnt, 0, sizeof(unsigned long long), a.s));
         a.last = depth + 1 == p->max_depth;
@@ -2254,10 +2255,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
             local.rays_at_depth[a.depth] += a.n;
             local.rays_total += a.n;
             const TailArgs ta = {a.result, cap, a.depth, p->max_depth, d_tail, tail_shade_min};
-            int            r  = timed(1, a.depth, a.s, [&] {
-                (void)launch_trace(sc, a.qin.base, cap, a.n, a.hits.base, cap, a.s, false, sc->d_counters, literal, a.work, true, &ta);
+            int            lrc = RTX_OK;
+            int            r   = timed(1, a.depth, a.s, [&] {
+                lrc = launch_trace(sc, a.qin.base, cap, a.n, a.hits.base, cap, a.s, false, sc->d_counters, literal, a.work, true, &ta);
             });
-            if (r != RTX_OK) return r;
+            if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
             local.trace_launches++;
             tail_used = true;
             a.n       = 0; // nothing is left for a further pass
