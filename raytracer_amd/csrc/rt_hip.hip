@@ -21,6 +21,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "rtx.h"
@@ -171,6 +174,34 @@ extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
 #define TAIL_COUNTERS 80 // u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
+// body(lo, hi) over [0, n) in contiguous ranges on the host's cores (RTX_HOST_THREADS, default up to 16): the per-node
+// and per-triangle passes of rtx_scene_create.  Results do not depend on the split.
+template <class F> static void parallel_ranges(size_t n, F&& body)
+{
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > 16) T = 16;
+    if (const char* e = getenv("RTX_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) T = (unsigned)v;
+    }
+    if (n < (1u << 15)) T = 1;
+    if (T == 1) {
+        body((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < T; k++) th.emplace_back([&body, n, k, T] { body(n * k / T, n * (k + 1) / T); });
+    body((size_t)0, n / T);
+    for (auto& t : th) t.join();
+}
+
+struct HostTimer { // RTX_HOST_TIMING=1: phases of rtx_scene_create on stderr
+    bool   on = getenv("RTX_HOST_TIMING") != nullptr;
+    double t0 = now();
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    void lap(const char* what) { if (on) { const double t = now(); fprintf(stderr, "rtx_scene_create: %-28s %.3f s\n", what, t - t0); t0 = t; } }
+};
 static int validate_desc(const rtx_scene_desc* d)
 {
     if (!d) return fail(RTX_E_INVALID, "null scene description");
@@ -263,12 +294,12 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     const size_t T = d->n_tris, Sn = d->n_spheres, N = d->n_nodes;
     // scene bounds -> centre, radius; rays are culled only while their origin is within RO of the centre
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (size_t i = 0; i < T; i++)
-        for (int v = 0; v < 3; v++)
-            for (int a = 0; a < 3; a++) {
-                double x = d->tri_pos[(3 * v + a) * T + i];
-                lo[a] = std::min(lo[a], x), hi[a] = std::max(hi[a], x);
-            }
+    for (int c = 0; c < 9; c++) { // min / max are exact: any order of the comparisons gives the same bounds
+        const float* col = d->tri_pos + (size_t)c * T;
+        float        mn = INFINITY, mx = -INFINITY;
+        for (size_t i = 0; i < T; i++) mn = col[i] < mn ? col[i] : mn, mx = col[i] > mx ? col[i] : mx;
+        if (T) lo[c % 3] = std::min(lo[c % 3], (double)mn), hi[c % 3] = std::max(hi[c % 3], (double)mx);
+    }
     for (size_t i = 0; i < Sn; i++)
         for (int a = 0; a < 3; a++) {
             double x = d->sph[a * Sn + i], r = fabs((double)d->sph[3 * Sn + i]);
@@ -278,14 +309,16 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     for (int a = 0; a < 3; a++) c[a] = 0.5 * (lo[a] + hi[a]), R += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
     R               = sqrt(R) + 1e-6;
     const double RO = 3.0 * R, D = 1.01 * (RO + R), SAFETY = 1.25;
-    std::vector<float> betas;
-    betas.reserve(T);
+    std::vector<float> betas(T);
     for (int a = 0; a < 3; a++) out.c[a] = (float)c[a];
     out.ro2 = round_down(RO * RO * 0.999);
 
     std::vector<double> plo(3 * (T + Sn)), phi(3 * (T + Sn)); // padded primitive bounds
     double              kappa_scene = 0.0;
-    for (size_t i = 0; i < T; i++) {
+    std::mutex          kmx;
+    parallel_ranges(T, [&](size_t t_lo, size_t t_hi) {
+    double kappa_part = 0.0;
+    for (size_t i = t_lo; i < t_hi; i++) {
         float p[9];
         for (int k = 0; k < 9; k++) p[k] = d->tri_pos[k * T + i];
         const float  e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
@@ -295,8 +328,8 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
         const bool   finite = std::isfinite(E) && kappa < 0.25;
         const double beta  = finite ? SAFETY * ((7.5 * EPS * D * E / ALPHA + kappa + EPS) / (1.0 - kappa)) : 0.0;
         const double tau   = finite ? SAFETY * (7.5 * EPS * D * E * E / ALPHA) / (1.0 - kappa) : 0.0;
-        if (finite) kappa_scene = std::max(kappa_scene, SAFETY * (kappa + 2.0 * EPS) / (1.0 - kappa));
-        betas.push_back(finite ? (float)beta : INFINITY);
+        if (finite) kappa_part = std::max(kappa_part, SAFETY * (kappa + 2.0 * EPS) / (1.0 - kappa));
+        betas[i] = finite ? (float)beta : INFINITY;
         for (int a = 0; a < 3; a++) {
             // bounds over v0, v1, v2 and v0 + e1, v0 + e2 as the kernel's records hold them
             double x0 = p[a], x1 = p[3 + a], x2 = p[6 + a], y1 = (double)p[a] + e1[a], y2 = (double)p[a] + e2[a];
@@ -306,6 +339,9 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
             phi[3 * i + a] = finite ? mx + pad : INFINITY;
         }
     }
+    std::lock_guard<std::mutex> g(kmx);
+    kappa_scene = std::max(kappa_scene, kappa_part);
+    });
     for (size_t i = 0; i < Sn; i++) {
         const double r = fabs((double)d->sph[3 * Sn + i]), Delta = 24.0 * EPS * (D * D + r * r);
         const double pad = SAFETY * (3.0 * sqrt(Delta) + 5.0 * EPS * D) + 32.0 * EPS * D;
@@ -322,26 +358,43 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     }
 
     // subtree boxes, children before parents (explicit stack: the tree can be 60 levels deep but is not balanced)
-    std::vector<double>   blo(3 * N, INFINITY), bhi(3 * N, -INFINITY);
-    std::vector<uint32_t> order, st;
-    order.reserve(N);
-    st.push_back(d->root_index);
-    while (!st.empty()) {
-        uint32_t n = st.back();
-        st.pop_back();
-        order.push_back(n);
-        if ((d->node_w1[n] >> 30) != 3u) st.push_back(n + 1), st.push_back(d->node_w1[n] & 0x3FFFFFFFu);
-    }
-    for (size_t k = order.size(); k-- > 0;) {
-        const uint32_t n = order[k];
-        if ((d->node_w1[n] >> 30) == 3u) {
+    std::unique_ptr<double[]> blo_mem(new double[3 * N]), bhi_mem(new double[3 * N]); // filled below, node by node
+    double* const             blo = blo_mem.get();
+    double* const             bhi = bhi_mem.get();
+    // leaves first, on all cores (the random reads of the primitives' bounds are most of this pass); an empty leaf
+    // and, for now, every inner node get the empty box
+    parallel_ranges(N, [&](size_t n_lo, size_t n_hi) {
+        for (size_t n = n_lo; n < n_hi; n++) {
+            for (int a = 0; a < 3; a++) blo[3 * n + a] = INFINITY, bhi[3 * n + a] = -INFINITY;
+            if ((d->node_w1[n] >> 30) != 3u) continue;
             const uint32_t len = d->node_w0[n], first = d->node_w1[n] & 0x3FFFFFFFu;
             for (uint32_t j = 0; j < len; j++) {
                 const uint32_t r = d->leaf_ref[first + j];
                 const size_t   p = (r & RTX_REF_SPHERE) ? T + (r & 0x7FFFFFFFu) : r;
                 for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * n + a], plo[3 * p + a]), bhi[3 * n + a] = std::max(bhi[3 * n + a], phi[3 * p + a]);
             }
-        } else {
+        }
+    });
+    std::vector<uint32_t> order, st;
+    // KDTree_New numbers a node before its subtrees (right child = node + 1, left child further on: kdtree.c:137-171),
+    // so the plain index order, backwards, has the children before the parents; any other numbering gets the
+    // order from a walk
+    bool preorder = true;
+    for (size_t n = 0; n < N && preorder; n++)
+        if ((d->node_w1[n] >> 30) != 3u && (d->node_w1[n] & 0x3FFFFFFFu) <= n) preorder = false;
+    if (!preorder) {
+        order.reserve(N);
+        st.push_back(d->root_index);
+        while (!st.empty()) {
+            uint32_t n = st.back();
+            st.pop_back();
+            order.push_back(n);
+            if ((d->node_w1[n] >> 30) != 3u) st.push_back(n + 1), st.push_back(d->node_w1[n] & 0x3FFFFFFFu);
+        }
+    }
+    for (size_t k = preorder ? N : order.size(); k-- > 0;) {
+        const uint32_t n = preorder ? (uint32_t)k : order[k];
+        if ((d->node_w1[n] >> 30) != 3u) { // inner nodes, children before parents
             const uint32_t l = d->node_w1[n] & 0x3FFFFFFFu, r = n + 1;
             for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * l + a], blo[3 * r + a]), bhi[3 * n + a] = std::max(bhi[3 * l + a], bhi[3 * r + a]);
         }
@@ -368,7 +421,8 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
         out.lo[a]        = (float)glo[a];
     }
     out.q16.assign(6 * N, 0);
-    for (size_t n = 0; n < N; n++) {
+    parallel_ranges(N, [&](size_t n_lo, size_t n_hi) {
+    for (size_t n = n_lo; n < n_hi; n++) {
         uint16_t* q      = &out.q16[6 * n];
         bool      nocull = false;
         for (int a = 0; a < 3; a++) {
@@ -384,6 +438,7 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
         }
         if (nocull) q[0] = 0xFFFF, q[3] = 0;
     }
+    });
 }
 
 // a box as the kernel reads it: {x, y, z}, max << 16 | min
@@ -413,7 +468,9 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     int n = 0, rc;
     if ((rc = rtx_device_count(&n)) != RTX_OK) return rc;
     if (device < 0 || device >= n) return fail(RTX_E_NO_DEVICE, "device %d not present (%d visible)", device, n);
+    HostTimer tm;
     if ((rc = validate_desc(d)) != RTX_OK) return rc;
+    tm.lap("validate");
     HIPCHECK(hipSetDevice(device));
 
     rtx_scene* sc = new rtx_scene();
@@ -438,12 +495,15 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         for (uint32_t i = 0; i < d->n_nodes; i++) nodes[i] = make_uint2(d->node_w0[i], d->node_w1[i]);
         UP(upload(sc, nodes.data(), nodes.size(), &S.nodes));
     }
+    tm.lap("nodes");
     {
         CullData cd;
         build_cull_data(d, cd);
+        tm.lap("culling boxes");
         {
             std::vector<uint4> n32(2 * (size_t)d->n_nodes, make_uint4(0, 0, 0, 0));
-            for (uint32_t i = 0; i < d->n_nodes; i++) {
+            parallel_ranges(d->n_nodes, [&](size_t i_lo, size_t i_hi) {
+            for (size_t i = i_lo; i < i_hi; i++) {
                 uint32_t l[3] = {0, 0, 0}, r[3] = {0, 0, 0};
                 if ((d->node_w1[i] >> 30) != 3u) { // indices checked by validate_desc
                     pack_box(&cd.q16[6 * (size_t)(d->node_w1[i] & 0x3FFFFFFFu)], l);
@@ -452,6 +512,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
                 n32[2 * (size_t)i]     = make_uint4(d->node_w0[i], d->node_w1[i], l[0], l[1]);
                 n32[2 * (size_t)i + 1] = make_uint4(l[2], r[0], r[1], r[2]);
             }
+            });
             UP(upload(sc, n32.data(), n32.size(), &S.nodes32));
             pack_box(&cd.q16[6 * (size_t)d->root_index], S.root_q);
         }
@@ -461,6 +522,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         for (int a = 0; a < 3; a++) S.bin_inv[a] = (float)(1 << BIN_CELL_BITS) / (cd.scale[a] * 65535.0f); // cells over the box grid
         sc->cull_useful = cd.useful;
     }
+    tm.lap("32-byte nodes");
     {
         // Device-side triangle order = order of first appearance in the leaf reference stream (the
         // tree's depth-first leaf order).  Triangles of one leaf, and of leaves that are neighbours
@@ -491,7 +553,8 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
 
         std::vector<float4>   hot((size_t)TRI_STRIDE * T), cold(4 * T);
         std::vector<uint32_t> obj(T);
-        for (size_t j = 0; j < T; j++) {
+        parallel_ranges(T, [&](size_t j_lo, size_t j_hi) {
+        for (size_t j = j_lo; j < j_hi; j++) {
             const size_t i = old_of_new[j];
             float        p[9], nn[9], uv[6];
             for (int c = 0; c < 9; c++) p[c] = d->tri_pos[c * T + i], nn[c] = d->tri_nrm[c * T + i];
@@ -511,10 +574,12 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
             cold[4 * j + 3] = make_float4(uv[3], uv[4], uv[5], matf);
             obj[j]          = d->tri_obj[i];
         }
+        });
         UP(upload(sc, hot.data(), hot.size(), &S.tri));
         UP(upload(sc, cold.data(), cold.size(), &S.tri_shade));
         UP(upload(sc, obj.data(), T, &S.tri_obj));
     }
+    tm.lap("triangle records");
     {
         const size_t          Sn = d->n_spheres;
         std::vector<float4>   sp(Sn);
@@ -558,6 +623,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         sc->d_counters = (uint64_t*)c;
     }
 #undef UP
+    tm.lap("the rest");
     S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
     S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root = d->root_index;
     for (int i = 0; i < 6; i++) S.skybox_tex[i] = d->skybox_tex[i];
@@ -1848,15 +1914,14 @@ struct DevBuf { // RAII device buffer for the host-pointer entry points
 
 static int trace_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine,
-        // 3: 2 + subtree-box culling, 4: 3 + cooperative leaves (default), 5: 2 + cooperative leaves.
-        // 0..2 and 5 walk the tree literally.
+    // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine,
+    // 3: 2 + subtree-box culling, 4: 3 + cooperative leaves (default), 5: 2 + cooperative leaves.
+    // 0..2 and 5 walk the tree literally.  (Read once; initialisation of a local static is thread-safe.)
+    static const int v = [] {
         const char* e = getenv("RTX_TRACE_VARIANT");
-        v             = e ? atoi(e) : 4;
-        if (v < 0 || v > 5) v = 4;
-    }
+        const int   x = e ? atoi(e) : 4;
+        return (x < 0 || x > 5) ? 4 : x;
+    }();
     return v;
 }
 
@@ -1894,15 +1959,14 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t,
                                   TailArgs);
     if (tail && (variant < 4 || count)) return fail(RTX_E_INVALID, "no tail variant of this closest-hit kernel");
-    static uint32_t tune = 0;
-    if (tune == 0) { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes)
+    static const uint32_t tune = [tv] { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes); read once
         unsigned    a = 16, b = 8, c = REFILL_MIN;
         if (tv >= 4) a = 4; // cooperative leaves fill their 64 slots from few lanes
         const char* e = getenv("RTX_TRACE_TUNE");
         if (e) sscanf(e, "%u,%u,%u", &a, &b, &c);
         a = std::min(std::max(a, 1u), 64u), b = std::min(std::max(b, 1u), 64u), c = std::min(std::max(c, 1u), 64u);
-        tune = a | b << 8 | c << 16;
-    }
+        return a | b << 8 | c << 16;
+    }();
     PersistKernel kern    = variant == 1   ? (count ? k_trace_persist<true> : k_trace_persist<false>)
                             : variant == 2 ? (count ? k_trace_flat<true, false, false> : k_trace_flat<false, false, false>)
                             : variant == 3 ? (count ? k_trace_flat<true, true, false> : k_trace_flat<false, true, false>)
@@ -2119,11 +2183,10 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     // pass it speeds up is too short to pay that back (tools/dbg/bands.py: a rank's share under an 8-way split)
     const char*     sm_env  = getenv("RTX_SORT_MIN");
     const long long bin_min = sm_env ? atoll(sm_env) : (4ll << 20);
-    static int sort_every = 0; // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
-    if (sort_every == 0) {
+    static const int sort_every = [] { // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
         const char* e = getenv("RTX_SORT_EVERY");
-        sort_every    = e ? std::max(1, atoi(e)) : 1;
-    }
+        return e ? std::max(1, atoi(e)) : 1;
+    }();
     if (!sc->h_alive) HIPCHECK(hipHostMalloc((void**)&sc->h_alive, RTX_MAX_LANES * sizeof(unsigned long long)));
     if (lanes > 1 && !sc->ev_fork) HIPCHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
     for (int l = 1; l < lanes; l++) {

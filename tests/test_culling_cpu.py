@@ -110,3 +110,50 @@ def test_boxes_contain_their_primitives(built_scenes):
             v = pos[:, r].reshape(3, 3)
             assert (v >= boxes[k, :3]).all() and (v <= boxes[k, 3:]).all()
     assert info[4] >= 1.0 and info[3] > 0 and not hip.cull_never(qbox[reach]).any()
+
+
+def test_boxes_do_not_depend_on_the_node_numbering(built_scenes):
+    """rtx_scene_create accepts any numbering with right child = node + 1.  KDTree_New's (node before both subtrees)
+    lets the subtree boxes be filled by one backward scan; any other takes the order from a walk.  The teapot's
+    tree renumbered so that every left subtree comes BEFORE its parent's right spine must get the same boxes —
+    and the oracle must find the same hits in it."""
+    import ctypes as C
+    sc = built_scenes("teapot")
+    d = sc.desc.contents
+    n = d.n_nodes
+    w0 = np.ctypeslib.as_array(d.node_w0, (n,)).copy()
+    w1 = np.ctypeslib.as_array(d.node_w1, (n,)).copy()
+    new_of_old = np.full(n, -1, np.int64)
+    nxt = 0
+    stack = [("spine", int(d.root_index))]  # order(node) = order(left(s)) for s on node's right spine, then the spine itself
+    while stack:
+        what, k = stack.pop()
+        if what == "emit":
+            for s in k:
+                new_of_old[s] = nxt
+                nxt += 1
+            continue
+        spine = [k]
+        while (w1[spine[-1]] >> 30) != 3:
+            spine.append(spine[-1] + 1)
+        stack.append(("emit", spine))
+        for s in spine[:-1]:
+            stack.append(("spine", int(w1[s] & 0x3FFFFFFF)))
+    reach = new_of_old >= 0
+    assert nxt == reach.sum() == n
+    p0, p1 = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    inner = (w1 >> 30) != 3
+    p0[new_of_old] = w0
+    p1[new_of_old] = np.where(inner, (w1 & 0xC0000000) | new_of_old[np.where(inner, w1 & 0x3FFFFFFF, 0)].astype(np.uint32), w1)
+    assert (new_of_old[np.nonzero(inner)[0] + 1] == new_of_old[inner] + 1).all()            # right child = node + 1 still
+    assert (new_of_old[(w1 & 0x3FFFFFFF)[inner]] < new_of_old[inner]).any()                 # and it is no preorder
+    d2 = type(d)()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+    d2.node_w0 = p0.ctypes.data_as(C.POINTER(C.c_uint32))
+    d2.node_w1 = p1.ctypes.data_as(C.POINTER(C.c_uint32))
+    d2.root_index = int(new_of_old[d.root_index])
+    q1, i1 = hip.cull_data(sc.desc)
+    q2, i2 = hip.cull_data(C.pointer(d2))
+    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and np.array_equal(q2[new_of_old], q1)
+    rays = golden("trace_teapot.npz")["rays"][:4000]
+    _same(O.trace(C.pointer(d2), rays[:, :3], rays[:, 3:], cull=(q2, i2)), O.trace(sc.desc, rays[:, :3], rays[:, 3:]))
