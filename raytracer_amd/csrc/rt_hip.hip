@@ -173,7 +173,7 @@ extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
 #ifndef TAIL_MAX_DEFAULT
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
-#define TAIL_COUNTERS 80 // u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
+#define TAIL_COUNTERS 160 // [80 + 8 k]: paths shaded by k_shade, spread over 8 counters; u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
 // body(lo, hi) over [0, n) in contiguous ranges on the host's cores (RTX_HOST_THREADS, default up to 16): the per-node
 // and per-triangle passes of rtx_scene_create.  Results do not depend on the split.
 template <class F> static void parallel_ranges(size_t n, F&& body)
@@ -1549,7 +1549,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
 // (1024-thread blocks: the two counters are bumped once per block.  With 256-thread blocks and a
 // per-wave atomic the 2.6 M same-address atomics of a 1080p/64 spp pass, ~12 ns each, WERE the kernel's
 // run time — rocprof: 6 % VALU busy, 84 % of wave time waiting.)
+#ifndef SHADE_BLOCK
 #define SHADE_BLOCK 1024
+#endif
 DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d);
 DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint32_t& base);
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
@@ -1615,7 +1617,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
         uint32_t total = 0, sh = 0;
         for (uint32_t w = 0; w < SHADE_BLOCK / 64; w++) total += s_wave_cnt[w], sh += s_wave_shaded[w];
         s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
-        if (sh) atomicAdd(shaded_count, (unsigned long long)sh);
+        if (sh) atomicAdd(shaded_count + 8 * (blockIdx.x & 7u), (unsigned long long)sh); // statistics only: 8 counters, 64 bytes apart
     }
     __syncthreads();
     if (alive) {
@@ -2195,7 +2197,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         HIPCHECK(hipEventCreateWithFlags(&sc->ev_join[l - 1], hipEventDisableTiming));
     }
 
-    unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[4];
+    unsigned long long* d_shaded = (unsigned long long*)&sc->d_counters[RTX_MAX_LANES * 80 + 80];
     HIPCHECK(hipMemsetAsync(sc->d_counters, 0, 16 * sizeof(uint64_t), st));
     // The tail of the bounce loop in one launch (k_trace_flat<..., TAIL>): once a lane's queue is too short to fill the
     // chip, a pass per depth costs more in ramps and drains than in work.  RTX_TAIL_MAX = longest queue handed to it
@@ -2379,7 +2381,11 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     uint64_t c[16];
     HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
     local.visits_inner = c[0], local.visits_leaf = c[1], local.visits_prim = c[2], local.visits_culled = c[3];
-    local.hits_shaded  = c[4];
+    {
+        uint64_t sh[64];
+        HIPCHECK(hipMemcpy(sh, d_shaded, sizeof sh, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) local.hits_shaded += sh[8 * k];
+    }
     for (int i = 0; i < 8; i++) local.wave_stats[i] = c[8 + i];
     if (tail_used) {
         uint64_t tc[RTX_MAX_DEPTH + 1];
