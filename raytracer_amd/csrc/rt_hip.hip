@@ -33,9 +33,12 @@
 
 // ray binning between bounce passes (see k_bin_count): cells per axis = 2^BIN_CELL_BITS, times 8 direction octants
 #ifndef BIN_CELL_BITS
-#define BIN_CELL_BITS 5
+#define BIN_CELL_BITS 6 // 64^3 cells x 8 octants = 2^21 bins (32^3: +0.75 ms per bench frame; spread3 takes at most 6 bits)
 #endif
-#define BIN_BITS (3 * BIN_CELL_BITS + 3)
+#ifndef BIN_DIR_EXTRA
+#define BIN_DIR_EXTRA 0 // 2: the direction's dominant axis joins the octant in the key (experiment)
+#endif
+#define BIN_BITS (3 * BIN_CELL_BITS + 3 + BIN_DIR_EXTRA)
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -1666,7 +1669,13 @@ DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d)
         c[a]    = (uint32_t)f;
     }
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+#if BIN_DIR_EXTRA == 2
+    const float    ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const uint32_t dom = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+    return ((spread3(c[0]) | spread3(c[1]) << 1 | spread3(c[2]) << 2) << 3 | oct) << 2 | dom;
+#else
     return (spread3(c[0]) | spread3(c[1]) << 1 | spread3(c[2]) << 2) << 3 | oct;
+#endif
 }
 
 // One atomic per wave and distinct key: neighbours in the queue mostly share a bin, and same-address atomics
@@ -1700,13 +1709,18 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
 // Exclusive prefix sums of the 2^BIN_BITS bin counts, in two short launches (one 1024-thread block walking all of them
 // took 100 us, on the critical path of every binned pass): each block scans its own 1024 counts in place and
 // leaves their total in chunk[block]; one more block turns the chunk totals into chunk bases, which the scatter adds.
-#define BIN_CHUNKS ((1u << BIN_BITS) / 1024u)
+#define BIN_SCAN_SHIFT (BIN_BITS > 20 ? BIN_BITS - 20 : 0) // counts per thread of k_bin_scan = 1 << BIN_SCAN_SHIFT: at most 1024 chunks
+#define BIN_CHUNK_SHIFT (10 + BIN_SCAN_SHIFT)
+#define BIN_CHUNKS ((1u << BIN_BITS) >> BIN_CHUNK_SHIFT)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ chunk)
 {
     __shared__ uint32_t s_w[16];
+    constexpr uint32_t  PER = 1u << BIN_SCAN_SHIFT;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t i   = blockIdx.x * 1024u + tid;
-    const uint32_t c   = counts[i];
+    const uint32_t i   = (blockIdx.x * 1024u + tid) * PER;
+    uint32_t       v[PER], c = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) v[k] = counts[i + k], c += v[k];
     const uint32_t inc = wave_scan_add(c);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
@@ -1715,7 +1729,9 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ counts
         if (w < wave) before += s_w[w];
         total += s_w[w];
     }
-    counts[i] = before + inc - c;
+    uint32_t run = before + inc - c;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) counts[i + k] = run, run += v[k];
     if (tid == 0) chunk[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(BIN_CHUNKS) void k_bin_scan_chunks(uint32_t* __restrict__ chunk)
@@ -1737,7 +1753,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, cons
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint2    ks  = keys[i]; // bin, slot inside the bin
-    const uint64_t pos = (uint64_t)offsets[ks.x] + chunk[ks.x >> 10] + ks.y;
+    const uint64_t pos = (uint64_t)offsets[ks.x] + chunk[ks.x >> BIN_CHUNK_SHIFT] + ks.y;
     // the destination is an AoS queue: one 64-byte record = one line per path, instead of 14 dwords on 14 lines
     uint32_t w[Q_RECORD];
 #pragma unroll
