@@ -554,7 +554,8 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         }
         UP(upload(sc, refs.data(), refs.size(), &S.leaf_ref));
 
-        std::vector<float4>   hot((size_t)TRI_STRIDE * T), cold(4 * T);
+        std::vector<float>    hot((size_t)(TRI_BYTES / 4) * T + 4, 0.0f); // + 16 bytes: the last record is read as three float4
+        std::vector<float4>   cold(4 * T);
         std::vector<uint32_t> obj(T);
         parallel_ranges(T, [&](size_t j_lo, size_t j_hi) {
         for (size_t j = j_lo; j < j_hi; j++) {
@@ -565,9 +566,8 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
             // edge1 = v1 - v0, edge2 = v2 - v0 (surfaces.c:137-138), one binary32 subtraction each
             float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
             float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
-            hot[TRI_STRIDE * j + 0]  = make_float4(p[0], p[1], p[2], e1x);
-            hot[TRI_STRIDE * j + 1]  = make_float4(e1y, e1z, e2x, e2y);
-            hot[TRI_STRIDE * j + 2]  = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+            float* h = &hot[(size_t)(TRI_BYTES / 4) * j];
+            h[0] = p[0], h[1] = p[1], h[2] = p[2], h[3] = e1x, h[4] = e1y, h[5] = e1z, h[6] = e2x, h[7] = e2y, h[8] = e2z;
             uint32_t mat    = d->tri_mat[i];
             float    matf;
             memcpy(&matf, &mat, 4);
@@ -578,7 +578,11 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
             obj[j]          = d->tri_obj[i];
         }
         });
-        UP(upload(sc, hot.data(), hot.size(), &S.tri));
+        {
+            const float* dtri = nullptr;
+            UP(upload(sc, hot.data(), hot.size(), &dtri));
+            S.tri = (const float4*)dtri;
+        }
         UP(upload(sc, cold.data(), cold.size(), &S.tri_shade));
         UP(upload(sc, obj.data(), T, &S.tri_obj));
     }
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
                 if (r & RTX_REF_SPHERE) {
                     hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
                 } else {
-                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
+                    const float4* tp = TRI_PTR(S, r);
                     const float4  a = tp[0], b = tp[1], c = tp[2];
                     hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, RT_EPSILON, tMax, t, u, v);
                 }
@@ -1361,7 +1365,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 if (refS & RTX_REF_SPHERE) {
                     hitS = Sphere_HitAt(S.sph[refS & 0x7FFFFFFFu], so, sd, RT_EPSILON, sT, tS);
                 } else {
-                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * refS;
+                    const float4* tp = TRI_PTR(S, refS);
                     float4        a  = tp[0];
 #if TRI_WAIT
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)::"memory");
@@ -1409,8 +1413,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 float t;
                 if (Sphere_HitAt(S.sph[r0 & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t) && t < bestT) bestT = t, best = r0, bu = 0.0f, bv = 0.0f;
             } else {
-                const float4* tpA = S.tri + (uint64_t)TRI_STRIDE * r0;
-                const float4* tpB = S.tri + (uint64_t)TRI_STRIDE * (pair ? r1 : r0);
+                const float4* tpA = TRI_PTR(S, r0);
+                const float4* tpB = TRI_PTR(S, (pair ? r1 : r0));
                 float4        aA = tpA[0], aB = tpB[0];
 #if TRI_WAIT
                 // One L2 request per triangle instead of three: a vector-L1 miss is not merged with a miss already
@@ -2132,7 +2136,9 @@ static int check_params(const rtx_render_params* p, FrameGeom* g, uint32_t* rows
     return RTX_OK;
 }
 
+#ifndef PATH_TILE
 #define PATH_TILE 32u
+#endif
 
 static int get_event(rtx_scene* sc, int i, hipEvent_t* ev)
 {

@@ -15,9 +15,13 @@
 #define PI32 3.141592653589793238462643383279502884197169399375105820f // src/math/math.h:7
 #define RTX_INF (__builtin_inff())
 #define RTX_STACK 64 // >= desc.max_depth (checked at rtx_scene_create)
-#ifndef TRI_STRIDE
-#define TRI_STRIDE 4 // float4 per hot triangle record: 64 B, one cache line each (36 B used)
+#ifndef TRI_BYTES
+#define TRI_BYTES 36 // bytes per hot triangle record, a multiple of 4, 36 used.  Packed beats one 64-byte line per
+                     // triangle: 108.0 / 107.2 / 106.6 / 106.6 ms per bench frame for 64 / 48 / 40 / 36 bytes
 #endif
+// a record is read as float4 [0], [1] and the first float of [2] (some kernels read all of [2]: the pool is padded);
+// the address is only 4-byte aligned when TRI_BYTES is no multiple of 16, which global loads allow
+#define TRI_PTR(S, r) ((const float4*)((const char*)(S).tri + (uint64_t)TRI_BYTES * (r)))
 #ifndef TRI_WAIT
 #define TRI_WAIT 1
 #endif
@@ -47,7 +51,7 @@ struct SceneDev {
     float           cull_lo[3], cull_scale[3], cull_magic[3];
     float           bin_inv[3]; // ray binning: 32 cells per axis over the box grid, cell = (o - cull_lo) * bin_inv
     const uint32_t* leaf_ref; // pool bit | pool index
-    // hot triangle pool, 16 * TRI_STRIDE bytes per triangle:
+    // hot triangle pool, TRI_BYTES bytes per triangle:
     //   [0] = v0.x v0.y v0.z e1.x   [1] = e1.y e1.z e2.x e2.y   [2] = e2.z 0 0 0
     // e1 = v1-v0, e2 = v2-v0: the two subtractions Triangle_HitAt redoes on every call
     // (src/rt/surfaces.c:137-138), hoisted to upload time; the rounded results are identical.
@@ -427,7 +431,7 @@ DEV void closest_hit(const SceneDev& S, const RayD& ray, uint32_t& ref, float& t
                 if (r & RTX_REF_SPHERE) {
                     hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], ray.o, ray.d, RT_EPSILON, tMax, t);
                 } else {
-                    const float4* tp = S.tri + (uint64_t)TRI_STRIDE * r;
+                    const float4* tp = TRI_PTR(S, r);
                     const float4  a = tp[0], b = tp[1], c = tp[2];
                     hit = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), ray.o, ray.d, RT_EPSILON,
                                          tMax, t, u, v);
