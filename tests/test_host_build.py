@@ -349,3 +349,12 @@ def test_camera_block_layout_matches_rtx_camera(built_scenes):
     assert list(cam.origin) == [20.0, -20.0, 20.0] and cam.lens_radius == 0.0
     w = np.array(list(cam.w))
     assert abs(np.linalg.norm(w) - 1) < 1e-6
+
+
+def test_obj_import_memory_rejects_null_arguments():
+    L = host.lib()
+    m = L.Mesh_New()
+    assert not L.Mesh_Import_OBJ_Memory(None, b"v 0 0 0\n", 8) and host.last_error()
+    assert not L.Mesh_Import_OBJ_Memory(m, None, 8)
+    assert L.Mesh_Import_OBJ_Memory(m, None, 0) and L.Mesh_Triangle_Count(m) == 0  # an empty file is an empty mesh
+    L.Mesh_Delete(m)
