@@ -19,7 +19,7 @@ for f in range(frames):
     _, _, st = ds.render(sc.rtx_camera(), hip.make_params(w, h, spp, depth, flags=flags), want_accum=False, want_bgr=False)
 out = {"scene": scene, "w": w, "h": h, "spp": spp, "depth": depth, "rays": st["rays_at_depth"],
        "ms": [round(x, 3) for x in st["ms_trace_at_depth"]],
-       "mrays_s": [round(r / m / 1e3, 1) for r, m in zip(st["rays_at_depth"], st["ms_trace_at_depth"])],
+       "mrays_s": [round(r / m / 1e3, 1) if m > 0 else None for r, m in zip(st["rays_at_depth"], st["ms_trace_at_depth"])],  # None: depth ran inside the tail launch
        "ms_trace": st["ms_trace"], "ms_shade": st["ms_shade"], "ms_sort": st["ms_sort"], "ms_total": st["ms_total"],
        "total_mrays_s": st["rays_total"] / st["ms_total"] / 1e3}
 if flags:
