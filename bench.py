@@ -13,7 +13,7 @@ f32 accumulation buffer, reduced to rank 0 (RCCL, only for N > 1) and tone-mappe
 For N > 1 launch as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-one rank per GPU; the same frame is split by interleaved 16-row bands ("strong" scaling: the total
+one rank per GPU; the same frame is split by interleaved 8-row bands ("strong" scaling: the total
 work is fixed), timed between barriers, MAX over ranks; rank 0 prints ONE JSON line.
 
 The oracle / reference binaries are used only for the `cpu_baseline` leg (rank 0, N = 1).

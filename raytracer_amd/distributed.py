@@ -27,7 +27,7 @@ class FramePlan:
     max_depth: int
     seed: tuple = (1, 2)
     split: str = "tile"  # "tile" | "sample"
-    band_rows: int = 16
+    band_rows: int = 8  # slowest rank at N = 8: 20.2 ms with 8-row bands, 20.8 with 16, 21.6 with 32 (tools/dbg/bandrows.py)
     flags: int = 0
     max_paths_in_flight: int = 0
 

@@ -11,7 +11,11 @@ n = int(os.environ.get("SHARE_N", "8"))
 best = None
 for _ in range(4):
     acc.zero_(); torch.cuda.synchronize(); t0 = time.time()
-    st = ds.render_device(cam, hip.make_params(W, H, spp, depth, band=(16, 0, n) if n > 1 else None), acc.data_ptr())
+    if os.environ.get("SHARE_SPLIT", "tile") == "sample":
+        prm = hip.make_params(W, H, spp, depth, sample_range=(0, spp // n))
+    else:
+        prm = hip.make_params(W, H, spp, depth, band=(int(os.environ.get("SHARE_BAND", "16")), 0, n) if n > 1 else None)
+    st = ds.render_device(cam, prm, acc.data_ptr())
     torch.cuda.synchronize(); dt = (time.time() - t0) * 1e3
     if best is None or dt < best[0]: best = (dt, st)
 dt, st = best
