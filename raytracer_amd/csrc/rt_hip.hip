@@ -663,6 +663,7 @@ struct FrameGeom {
     uint64_t seed_lo, seed_hi;
     uint32_t pixel_centres;
     uint32_t tile, slab_rows; // tile != 0: the slab is slab_rows whole rows and its paths are in tile-major pixel order
+    uint32_t tile_h;          // tiles are tile pixels wide and tile_h rows high
     // Random_Seed's jump (random.c:53-76) is linear over GF(2) in the seed words: jump(a, b) = XOR over the bytes of a of
     // jump_tab[byte position][byte value], XOR jump_b = jump(0, b).  8 lookups instead of 128 generator steps.
     const uint4* jump_tab; // 8 x 256 entries, or NULL: do the 128 steps
@@ -686,14 +687,14 @@ DEV void rng_seed_tab(Rng& r, uint64_t a, const FrameGeom& g)
 DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
 {
     if (g.tile == 0) return j;
-    const uint32_t W = g.width, R = g.slab_rows, T = g.tile;
-    const uint32_t tr = (uint32_t)(j / ((uint64_t)W * T));
-    const uint32_t rem = (uint32_t)(j - (uint64_t)tr * W * T);
-    const uint32_t h   = min(T, R - tr * T);
+    const uint32_t W = g.width, R = g.slab_rows, T = g.tile, TH = g.tile_h;
+    const uint32_t tr = (uint32_t)(j / ((uint64_t)W * TH));
+    const uint32_t rem = (uint32_t)(j - (uint64_t)tr * W * TH);
+    const uint32_t h   = min(TH, R - tr * TH);
     const uint32_t tc  = rem / (T * h);
     const uint32_t r2  = rem - tc * T * h;
     const uint32_t w   = min(T, W - tc * T);
-    return (uint64_t)(tr * T + r2 / w) * W + tc * T + r2 % w;
+    return (uint64_t)(tr * TH + r2 / w) * W + tc * T + r2 % w;
 }
 
 // k-th row assigned to this rank → image row
@@ -2122,7 +2123,7 @@ static int check_params(const rtx_render_params* p, FrameGeom* g, uint32_t* rows
     g->sample_begin = sb, g->n_samples = se - sb;
     g->seed_lo = p->seed_lo, g->seed_hi = p->seed_hi;
     g->pixel_centres = (p->flags & RTX_RENDER_PIXEL_CENTRES) ? 1 : 0;
-    g->tile = 0, g->slab_rows = 0;
+    g->tile = 0, g->slab_rows = 0, g->tile_h = 0;
     g->jump_tab = nullptr;
     memset(g->jump_b, 0, sizeof g->jump_b);
     uint32_t rows = 0;
@@ -2327,7 +2328,14 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         // (no clearing of the result slab: every path writes its slot exactly once — on a miss, when its material ends
         // it, or at the last depth — before the slab is resolved)
         a.gs = g; // tile-major path order when the slab is made of whole rows
-        if (a.px0 % g.width == 0 && a.npx % g.width == 0 && a.npx / g.width >= 2 * PATH_TILE) a.gs.tile = PATH_TILE, a.gs.slab_rows = (uint32_t)(a.npx / g.width);
+        if (a.px0 % g.width == 0 && a.npx % g.width == 0 && a.npx / g.width >= 2 * PATH_TILE) {
+            a.gs.tile = a.gs.tile_h = PATH_TILE, a.gs.slab_rows = (uint32_t)(a.npx / g.width);
+            // a rank's rows under the band split are bands from all over the image: a tile as high as a band (and as
+            // much wider) stays one compact region instead of a stack of strips band_world bands apart
+            static const bool band_tiles = !getenv("RTX_BAND_TILES") || atoi(getenv("RTX_BAND_TILES")) != 0;
+            if (band_tiles && g.band_rows && g.band_rows < PATH_TILE && a.px0 == 0 && a.gs.slab_rows % g.band_rows == 0)
+                a.gs.tile_h = g.band_rows, a.gs.tile = std::max<uint32_t>(PATH_TILE, PATH_TILE * PATH_TILE / g.band_rows);
+        }
         a.cur = 0, a.qin = soa(a, 0), a.depth = 0; // SoA out of raygen / shade, AoS out of the binning pass
         int r = timed(0, 0, a.s, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, *cam, a.gs, a.px0, a.n, soa(a, 0)); });
         return r != RTX_OK ? r : enqueue_depth(a);
