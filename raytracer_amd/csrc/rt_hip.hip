@@ -735,7 +735,26 @@ DEV void camera_sample(const rtx_camera& cam, const FrameGeom& g, uint32_t xx, u
     d         = vnorm(dir); // Ray_Make, ray.c:6
 }
 
-__global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uint64_t first_pixel, uint64_t n, Queue q)
+// the RNG state camera_sample leaves behind for path i of a slab (what k_raygen would have stored): the first shade
+// pass recomputes it instead of reading it back — 32 bytes less per camera path written and 32 read
+DEV Rng camera_rng(const FrameGeom& g, uint64_t first_pixel, uint64_t i)
+{
+    const uint64_t pl = first_pixel + slab_pixel(g, i / g.n_samples);
+    const uint32_t s  = g.sample_begin + (uint32_t)(i % g.n_samples);
+    const uint32_t xx = (uint32_t)(pl % g.width);
+    const uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+    const uint64_t pixel = (uint64_t)yy * g.width + xx;
+    Rng            rng;
+    if (g.jump_tab) rng_seed_tab(rng, g.seed_lo ^ (pixel * g.spp + s), g);
+    else rng_seed(rng, g.seed_lo ^ (pixel * g.spp + s), g.seed_hi);
+    if (!g.pixel_centres) (void)Random_Unilateral(rng), (void)Random_Unilateral(rng); // the jitter draws
+    float rx, ry;
+    Random_InDisc(rng, 0.0f, rx, ry); // the two lens draws (taken whatever the radius, camera.c:36)
+    return rng;
+}
+
+// lean: only origin and direction are stored; throughput (1), path id (i) and RNG state are rebuilt by the first shade pass
+__global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uint64_t first_pixel, uint64_t n, Queue q, int lean)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -748,6 +767,7 @@ __global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uin
     camera_sample(cam, g, xx, yy, s, rng, o, d);
     q.f(Q_OX, i) = o.x, q.f(Q_OY, i) = o.y, q.f(Q_OZ, i) = o.z;
     q.f(Q_DX, i) = d.x, q.f(Q_DY, i) = d.y, q.f(Q_DZ, i) = d.z;
+    if (lean) return;
     q.f(Q_TR, i) = 1.0f, q.f(Q_TG, i) = 1.0f, q.f(Q_TB, i) = 1.0f;
     q.u(Q_S0, i) = rng.s0, q.u(Q_S1, i) = rng.s1, q.u(Q_S2, i) = rng.s2, q.u(Q_S3, i) = rng.s3;
     q.u(Q_PID, i) = (uint32_t)i;
@@ -1565,7 +1585,8 @@ DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint3
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
                                                        unsigned long long* out_count, unsigned long long* shaded_count,
                                                        float* __restrict__ result, uint64_t rcap, int last,
-                                                       uint32_t* __restrict__ bin_cnt, uint2* __restrict__ bin_keys)
+                                                       uint32_t* __restrict__ bin_cnt, uint2* __restrict__ bin_keys, FrameGeom g,
+                                                       uint64_t first_pixel, int first)
 {
     __shared__ uint32_t s_wave_cnt[SHADE_BLOCK / 64], s_wave_shaded[SHADE_BLOCK / 64];
     __shared__ uint64_t s_base;
@@ -1578,8 +1599,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
     if (i < n) {
         f3 o = mk3(qin.f(Q_OX, i), qin.f(Q_OY, i), qin.f(Q_OZ, i));
         f3 d = mk3(qin.f(Q_DX, i), qin.f(Q_DY, i), qin.f(Q_DZ, i));
-        T    = mk3(qin.f(Q_TR, i), qin.f(Q_TG, i), qin.f(Q_TB, i));
-        pid  = qin.u(Q_PID, i);
+        // first: the queue comes from a lean k_raygen
+        T    = first ? mk3(1.0f, 1.0f, 1.0f) : mk3(qin.f(Q_TR, i), qin.f(Q_TG, i), qin.f(Q_TB, i));
+        pid  = first ? (uint32_t)i : qin.u(Q_PID, i);
         uint32_t ref = hits.base[0 * hits.cap + i];
         if (ref == HIT_MISS) { // Scene_Get_SkyColor(ray->dir), renderer.c:75
             f3 sky = Skybox_ColorAt(S, d);
@@ -1589,7 +1611,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
             float t = __uint_as_float(hits.base[1 * hits.cap + i]);
             float u = __uint_as_float(hits.base[2 * hits.cap + i]);
             float v = __uint_as_float(hits.base[3 * hits.cap + i]);
-            rng     = Rng{qin.u(Q_S0, i), qin.u(Q_S1, i), qin.u(Q_S2, i), qin.u(Q_S3, i)};
+            rng     = first ? camera_rng(g, first_pixel, i) : Rng{qin.u(Q_S0, i), qin.u(Q_S1, i), qin.u(Q_S2, i), qin.u(Q_S3, i)};
             HitD h  = make_hitinfo(S, o, d, ref, t, u, v);
             f3   surf, emit, dout;
             bool cont = Material_Bounce(S, S.mats[h.mat], d, h, rng, surf, emit, dout);
@@ -2231,6 +2253,9 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     const char*         ts_env   = getenv("RTX_TAIL_SHADE_MIN");
     const uint32_t      tail_shade_min = (uint32_t)std::min(64, std::max(1, ts_env ? atoi(ts_env) : 16));
     bool                tail_used = false;
+    // RTX_RAYGEN_LEAN=0: k_raygen stores whole path records and the first shade pass reads them (the tests compare the two)
+    const char*         lr_env      = getenv("RTX_RAYGEN_LEAN");
+    const bool          lean_raygen = !lr_env || atoi(lr_env) != 0;
     HIPCHECK(hipMemsetAsync(d_tail, 0, TAIL_COUNTERS * sizeof(uint64_t), st));
 
     int        nev = 0;
@@ -2310,7 +2335,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         if (a.bin) HIPCHECK(hipMemsetAsync(a.bin_cnt, 0, bin_bytes, a.s));
         r = timed(2, depth, a.s, [&] {
             hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, a.s, sc->dev, a.qin, a.hits, a.n, soa(a, a.cur ^ 1), a.d_cnt,
-                               d_shaded, a.result, cap, a.last ? 1 : 0, a.bin ? a.bin_cnt : nullptr, a.bin_keys);
+                               d_shaded, a.result, cap, a.last ? 1 : 0, a.bin ? a.bin_cnt : nullptr, a.bin_keys, a.gs, a.px0, depth == 0 && lean_raygen ? 1 : 0);
         });
         if (r != RTX_OK) return r;
         *a.h_alive = 0;
@@ -2337,7 +2362,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
                 a.gs.tile_h = g.band_rows, a.gs.tile = std::max<uint32_t>(PATH_TILE, PATH_TILE * PATH_TILE / g.band_rows);
         }
         a.cur = 0, a.qin = soa(a, 0), a.depth = 0; // SoA out of raygen / shade, AoS out of the binning pass
-        int r = timed(0, 0, a.s, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, *cam, a.gs, a.px0, a.n, soa(a, 0)); });
+        int r = timed(0, 0, a.s, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, *cam, a.gs, a.px0, a.n, soa(a, 0), lean_raygen ? 1 : 0); });
         return r != RTX_OK ? r : enqueue_depth(a);
     };
     auto advance = [&](Lane& a) -> int { // the lane's pass has finished: bin and go one deeper, or close the slab

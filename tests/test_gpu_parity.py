@@ -357,6 +357,25 @@ def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeyp
 
 
 @pytest.mark.gpu
+def test_first_shade_pass_rebuilds_what_raygen_does_not_store(built_scenes, device_scenes, monkeypatch):
+    """k_raygen stores only origin and direction; the first shade pass rebuilds throughput (1), path id and the RNG
+    state camera_sample leaves behind (seed jump + jitter + lens draws).  Same frame as with whole records
+    (RTX_RAYGEN_LEAN=0), bit for bit — jittered and pixel-centre rays, bands, sample ranges, slabs, both seed-jump forms."""
+    sc, ds = built_scenes("materials"), device_scenes("materials")
+    cam = sc.rtx_camera()
+    cases = [dict(), dict(flags=hip.RTX_RENDER_PIXEL_CENTRES), dict(band=(8, 1, 3)), dict(sample_range=(2, 5)), dict(max_paths_in_flight=3000)]
+    for kw in cases:
+        for jt in ("1", "0"):
+            monkeypatch.setenv("RTX_JUMP_TABLE", jt)
+            out = []
+            for lean in ("0", "1"):
+                monkeypatch.setenv("RTX_RAYGEN_LEAN", lean)
+                out.append(ds.render(cam, hip.make_params(97, 61, 6, 5, seed=(11, 12), **kw)))
+            assert np.array_equal(out[0][0], out[1][0]) and same_bits(out[0][1], out[1][1]), (kw, jt)
+            assert out[0][2]["rays_at_depth"] == out[1][2]["rays_at_depth"] and out[0][2]["hits_shaded"] == out[1][2]["hits_shaded"]
+
+
+@pytest.mark.gpu
 def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monkeypatch):
     """Frames whose sizes fit no tile, wave or slab boundary: one launch, tiny slabs, several lanes and a forced
     binning pass all give the same bits and trace the same rays."""
