@@ -656,6 +656,39 @@ struct Hits { // SoA: ref, t, u, v
     uint64_t  cap;
 };
 
+// Division of a 32-bit number by a divisor fixed for the launch: the generator steps per path and pixel index are
+// decoded with ten divisions, ~35 vector instructions each when the divisor is only known at run time (k_raygen spent
+// most of its time in them).  libdivide's branch-free u32 scheme: exact for every numerator.
+struct FastDiv {
+    uint32_t m, s; // s bit 31: divisor 1
+};
+static FastDiv fastdiv_gen(uint32_t d)
+{
+    FastDiv r;
+    if (d <= 1) {
+        r.m = 0, r.s = 0x80000000u;
+        return r;
+    }
+    const uint32_t fl = 31u - (uint32_t)__builtin_clz(d);
+    if ((d & (d - 1)) == 0) {
+        r.m = 0, r.s = fl - 1;
+        return r;
+    }
+    const uint64_t num = (uint64_t)(1ull << fl) << 32;
+    uint64_t       m   = num / d;
+    const uint64_t rem = num % d;
+    m += m;
+    if (rem + rem >= d) m += 1;
+    r.m = (uint32_t)(m + 1), r.s = fl;
+    return r;
+}
+DEV uint32_t fdiv(uint32_t n, FastDiv f)
+{
+    const uint32_t q = __umulhi(f.m, n);
+    const uint32_t t = ((n - q) >> 1) + q;
+    return (f.s & 0x80000000u) ? n : t >> (f.s & 31u);
+}
+
 struct FrameGeom {
     uint32_t width, height, spp;
     uint32_t band_rows, band_rank, band_world; // band_rows == 0: every row
@@ -668,7 +701,49 @@ struct FrameGeom {
     // jump_tab[byte position][byte value], XOR jump_b = jump(0, b).  8 lookups instead of 128 generator steps.
     const uint4* jump_tab; // 8 x 256 entries, or NULL: do the 128 steps
     uint32_t     jump_b[4];
+    // fast != 0: every index below fits 32 bits and the divisions go through these (geom_finish fills them)
+    uint32_t fast, h_edge, w_edge;
+    FastDiv  fd_ns, fd_w, fd_band, fd_trow, fd_th[2], fd_tw[2]; // n_samples, width, band_rows, width * tile_h, tile * {tile_h, h_edge}, {tile, w_edge}
 };
+
+// call after the last change to a FrameGeom's sizes / tiling
+static void geom_finish(FrameGeom& g)
+{
+    g.fast = 0;
+    if (getenv("RTX_FAST_DIV") && atoi(getenv("RTX_FAST_DIV")) == 0) return; // the tests compare the two
+    if ((uint64_t)g.width * g.height >= (1ull << 32) || g.n_samples == 0 || g.width == 0) return;
+    g.fd_ns   = fastdiv_gen(g.n_samples);
+    g.fd_w    = fastdiv_gen(g.width);
+    g.fd_band = fastdiv_gen(g.band_rows ? g.band_rows : 1);
+    if (g.tile) {
+        if ((uint64_t)g.width * g.tile_h >= (1ull << 32) || (uint64_t)g.tile * g.tile_h >= (1ull << 32)) return;
+        g.h_edge   = g.slab_rows % g.tile_h ? g.slab_rows % g.tile_h : g.tile_h;
+        g.w_edge   = g.width % g.tile ? g.width % g.tile : g.tile;
+        g.fd_trow  = fastdiv_gen(g.width * g.tile_h);
+        g.fd_th[0] = fastdiv_gen(g.tile * g.tile_h), g.fd_th[1] = fastdiv_gen(g.tile * g.h_edge);
+        g.fd_tw[0] = fastdiv_gen(g.tile), g.fd_tw[1] = fastdiv_gen(g.w_edge);
+    }
+    g.fast = 1;
+}
+
+// path index of a slab -> (pixel position in the slab, sample); pixel index of this rank's list -> (x, row of the list)
+DEV void split_path(const FrameGeom& g, uint64_t i, uint64_t& px, uint32_t& s)
+{
+    if (g.fast) {
+        const uint32_t q = fdiv((uint32_t)i, g.fd_ns);
+        px = q, s = (uint32_t)i - q * g.n_samples;
+    } else {
+        px = i / g.n_samples, s = (uint32_t)(i % g.n_samples);
+    }
+}
+DEV void split_pixel(const FrameGeom& g, uint64_t pl, uint32_t& x, uint32_t& row)
+{
+    if (g.fast) {
+        row = fdiv((uint32_t)pl, g.fd_w), x = (uint32_t)pl - row * g.width;
+    } else {
+        x = (uint32_t)(pl % g.width), row = (uint32_t)(pl / g.width);
+    }
+}
 
 DEV void rng_seed_tab(Rng& r, uint64_t a, const FrameGeom& g)
 {
@@ -688,6 +763,19 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
 {
     if (g.tile == 0) return j;
     const uint32_t W = g.width, R = g.slab_rows, T = g.tile, TH = g.tile_h;
+    if (g.fast) {
+        const uint32_t jj  = (uint32_t)j;
+        const uint32_t tr  = fdiv(jj, g.fd_trow);
+        const uint32_t rem = jj - tr * (W * TH);
+        const uint32_t h   = min(TH, R - tr * TH); // TH, or h_edge in the last row of tiles
+        const FastDiv  fh  = h != TH ? g.fd_th[1] : g.fd_th[0];
+        const uint32_t tc  = fdiv(rem, fh);
+        const uint32_t r2  = rem - tc * T * h;
+        const uint32_t w   = min(T, W - tc * T); // T, or w_edge in the last column
+        const FastDiv  fw  = w != T ? g.fd_tw[1] : g.fd_tw[0];
+        const uint32_t rr  = fdiv(r2, fw);
+        return (uint64_t)(tr * TH + rr) * W + tc * T + (r2 - rr * w);
+    }
     const uint32_t tr = (uint32_t)(j / ((uint64_t)W * TH));
     const uint32_t rem = (uint32_t)(j - (uint64_t)tr * W * TH);
     const uint32_t h   = min(TH, R - tr * TH);
@@ -701,7 +789,9 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
 DEV uint32_t assigned_row(const FrameGeom& g, uint32_t k)
 {
     if (g.band_rows == 0) return k;
-    uint32_t j = k / g.band_rows, within = k % g.band_rows;
+    uint32_t j, within;
+    if (g.fast) j = fdiv(k, g.fd_band), within = k - j * g.band_rows;
+    else j = k / g.band_rows, within = k % g.band_rows;
     return (g.band_rank + j * g.band_world) * g.band_rows + within;
 }
 
@@ -739,10 +829,12 @@ DEV void camera_sample(const rtx_camera& cam, const FrameGeom& g, uint32_t xx, u
 // pass recomputes it instead of reading it back — 32 bytes less per camera path written and 32 read
 DEV Rng camera_rng(const FrameGeom& g, uint64_t first_pixel, uint64_t i)
 {
-    const uint64_t pl = first_pixel + slab_pixel(g, i / g.n_samples);
-    const uint32_t s  = g.sample_begin + (uint32_t)(i % g.n_samples);
-    const uint32_t xx = (uint32_t)(pl % g.width);
-    const uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+    uint64_t px;
+    uint32_t s, xx, row;
+    split_path(g, i, px, s);
+    s += g.sample_begin;
+    split_pixel(g, first_pixel + slab_pixel(g, px), xx, row);
+    const uint32_t yy = assigned_row(g, row);
     const uint64_t pixel = (uint64_t)yy * g.width + xx;
     Rng            rng;
     if (g.jump_tab) rng_seed_tab(rng, g.seed_lo ^ (pixel * g.spp + s), g);
@@ -758,10 +850,12 @@ __global__ __launch_bounds__(256) void k_raygen(rtx_camera cam, FrameGeom g, uin
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t pl = first_pixel + slab_pixel(g, i / g.n_samples); // index in this rank's pixel list
-    uint32_t s  = g.sample_begin + (uint32_t)(i % g.n_samples);
-    uint32_t xx = (uint32_t)(pl % g.width);
-    uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+    uint64_t px;
+    uint32_t s, xx, row;
+    split_path(g, i, px, s);
+    s += g.sample_begin;
+    split_pixel(g, first_pixel + slab_pixel(g, px), xx, row); // first_pixel + ...: index in this rank's pixel list
+    uint32_t yy = assigned_row(g, row);
     Rng      rng;
     f3       o, d;
     camera_sample(cam, g, xx, yy, s, rng, o, d);
@@ -1808,9 +1902,9 @@ __global__ __launch_bounds__(256) void k_resolve_slab(const float* __restrict__ 
     uint64_t o = 0;
     float    cum[3] = {0.0f, 0.0f, 0.0f};
     if (p < n_pixels) {
-        const uint64_t pl = first_pixel + slab_pixel(g, p);
-        const uint32_t xx = (uint32_t)(pl % g.width);
-        const uint32_t yy = assigned_row(g, (uint32_t)(pl / g.width));
+        uint32_t xx, row;
+        split_pixel(g, first_pixel + slab_pixel(g, p), xx, row);
+        const uint32_t yy = assigned_row(g, row);
         o                 = ((uint64_t)yy * g.width + xx) * 3;
         cum[0] = accum[o + 0], cum[1] = accum[o + 1], cum[2] = accum[o + 2];
     }
@@ -2156,6 +2250,7 @@ static int check_params(const rtx_render_params* p, FrameGeom* g, uint32_t* rows
         for (uint32_t b = g->band_rank; b < nb; b += g->band_world) rows += std::min(g->band_rows, p->height - b * g->band_rows);
     }
     *rows_out = rows;
+    geom_finish(*g);
     return RTX_OK;
 }
 
@@ -2361,6 +2456,7 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
             if (band_tiles && g.band_rows && g.band_rows < PATH_TILE && a.px0 == 0 && a.gs.slab_rows % g.band_rows == 0)
                 a.gs.tile_h = g.band_rows, a.gs.tile = std::max<uint32_t>(PATH_TILE, PATH_TILE * PATH_TILE / g.band_rows);
         }
+        geom_finish(a.gs);
         a.cur = 0, a.qin = soa(a, 0), a.depth = 0; // SoA out of raygen / shade, AoS out of the binning pass
         int r = timed(0, 0, a.s, [&] { hipLaunchKernelGGL(k_raygen, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, *cam, a.gs, a.px0, a.n, soa(a, 0), lean_raygen ? 1 : 0); });
         return r != RTX_OK ? r : enqueue_depth(a);

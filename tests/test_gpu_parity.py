@@ -376,6 +376,25 @@ def test_first_shade_pass_rebuilds_what_raygen_does_not_store(built_scenes, devi
 
 
 @pytest.mark.gpu
+def test_fast_index_divisions_decode_the_same_pixels(built_scenes, device_scenes, monkeypatch):
+    """Path and pixel indices are decoded with multiply-shift divisions by the launch's fixed divisors (samples,
+    width, tile sizes, band height).  Same frames as with the plain divisions (RTX_FAST_DIV=0), bit for bit, on sizes
+    with ragged tiles, bands with a partial last band, sample ranges, slabs that cut the frame, one-sample and
+    two-pixel-wide frames."""
+    sc, ds = built_scenes("materials"), device_scenes("materials")
+    cam = sc.rtx_camera()
+    cases = [(130, 70, 3, 3, {}), (97, 131, 5, 3, dict(band=(8, 2, 3))), (64, 64, 1, 4, dict(band=(5, 0, 2))), (200, 66, 7, 2, dict(sample_range=(1, 4))),
+             (77, 200, 2, 3, dict(max_paths_in_flight=9000)), (2, 300, 4, 2, {}), (300, 2, 4, 2, {}), (129, 65, 64, 2, dict(band=(16, 1, 2)))]
+    for w, h, spp, depth, kw in cases:
+        out = []
+        for fd in ("0", "1"):
+            monkeypatch.setenv("RTX_FAST_DIV", fd)
+            out.append(ds.render(cam, hip.make_params(w, h, spp, depth, seed=(21, 22), **kw)))
+        assert np.array_equal(out[0][0], out[1][0]) and same_bits(out[0][1], out[1][1]), (w, h, spp, kw)
+        assert out[0][2]["rays_at_depth"] == out[1][2]["rays_at_depth"]
+
+
+@pytest.mark.gpu
 def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monkeypatch):
     """Frames whose sizes fit no tile, wave or slab boundary: one launch, tiny slabs, several lanes and a forced
     binning pass all give the same bits and trace the same rays."""

@@ -19,4 +19,4 @@ for _ in range(4):
     torch.cuda.synchronize(); dt = (time.time() - t0) * 1e3
     if best is None or dt < best[0]: best = (dt, st)
 dt, st = best
-print("%s N=%d wall %.2f | trace %.2f shade %.2f sort %.2f | per depth %s" % (os.environ.get("TAG", ""), n, dt, st["ms_trace"], st["ms_shade"], st["ms_sort"], [round(x, 2) for x in st["ms_trace_at_depth"]]), flush=True)
+print("%s N=%d wall %.2f | raygen %.2f resolve %.2f | trace %.2f shade %.2f sort %.2f | per depth %s" % (os.environ.get("TAG", ""), n, dt, st["ms_raygen"], st["ms_resolve"], st["ms_trace"], st["ms_shade"], st["ms_sort"], [round(x, 2) for x in st["ms_trace_at_depth"]]), flush=True)
