@@ -1691,11 +1691,24 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
     uint32_t  pid = 0;
     bool      shaded = false;
     if (i < n) {
-        f3 o = mk3(qin.f(Q_OX, i), qin.f(Q_OY, i), qin.f(Q_OZ, i));
-        f3 d = mk3(qin.f(Q_DX, i), qin.f(Q_DY, i), qin.f(Q_DZ, i));
-        // first: the queue comes from a lean k_raygen
-        T    = first ? mk3(1.0f, 1.0f, 1.0f) : mk3(qin.f(Q_TR, i), qin.f(Q_TG, i), qin.f(Q_TB, i));
-        pid  = first ? (uint32_t)i : qin.u(Q_PID, i);
+        f3         o, d;
+        const bool aos = qin.es == Q_RECORD; // binned queue: a 64-byte record per path, read as four 16-byte quarters
+        uint4      q2 = make_uint4(0, 0, 0, 0), q3 = q2;
+        if (aos) {
+            const uint4* rec = (const uint4*)((const uint32_t*)qin.base + i * Q_RECORD);
+            const uint4  q0 = rec[0], q1 = rec[1];
+            q2 = rec[2], q3 = rec[3];
+            o   = mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            d   = mk3(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y));
+            T   = mk3(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x));
+            pid = q3.y;
+        } else {
+            o = mk3(qin.f(Q_OX, i), qin.f(Q_OY, i), qin.f(Q_OZ, i));
+            d = mk3(qin.f(Q_DX, i), qin.f(Q_DY, i), qin.f(Q_DZ, i));
+            // first: the queue comes from a lean k_raygen
+            T    = first ? mk3(1.0f, 1.0f, 1.0f) : mk3(qin.f(Q_TR, i), qin.f(Q_TG, i), qin.f(Q_TB, i));
+            pid  = first ? (uint32_t)i : qin.u(Q_PID, i);
+        }
         uint32_t ref = hits.base[0 * hits.cap + i];
         if (ref == HIT_MISS) { // Scene_Get_SkyColor(ray->dir), renderer.c:75
             f3 sky = Skybox_ColorAt(S, d);
@@ -1705,7 +1718,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
             float t = __uint_as_float(hits.base[1 * hits.cap + i]);
             float u = __uint_as_float(hits.base[2 * hits.cap + i]);
             float v = __uint_as_float(hits.base[3 * hits.cap + i]);
-            rng     = first ? camera_rng(g, first_pixel, i) : Rng{qin.u(Q_S0, i), qin.u(Q_S1, i), qin.u(Q_S2, i), qin.u(Q_S3, i)};
+            rng     = aos ? Rng{q2.y, q2.z, q2.w, q3.x} : first ? camera_rng(g, first_pixel, i) : Rng{qin.u(Q_S0, i), qin.u(Q_S1, i), qin.u(Q_S2, i), qin.u(Q_S3, i)};
             HitD h  = make_hitinfo(S, o, d, ref, t, u, v);
             f3   surf, emit, dout;
             bool cont = Material_Bounce(S, S.mats[h.mat], d, h, rng, surf, emit, dout);
@@ -1871,18 +1884,33 @@ __global__ __launch_bounds__(BIN_CHUNKS) void k_bin_scan_chunks(uint32_t* __rest
 __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk,
                                                      const uint2* __restrict__ keys, Queue qout)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint2    ks  = keys[i]; // bin, slot inside the bin
-    const uint64_t pos = (uint64_t)offsets[ks.x] + chunk[ks.x >> BIN_CHUNK_SHIFT] + ks.y;
-    // the destination is an AoS queue: one 64-byte record = one line per path, instead of 14 dwords on 14 lines
-    uint32_t w[Q_RECORD];
+    // Each lane gathers its own path's 14 dwords (coalesced: the source is SoA); the records then go through LDS so
+    // that FOUR lanes store the four 16-byte quarters of ONE record in the same instruction — a store instruction
+    // covers 16 whole 64-byte lines instead of a quarter of 64 different ones.
+    __shared__ uint4    s_rec[256 * 4 + 256 / 16]; // [thread][quarter], one uint4 of padding per 16 threads
+    __shared__ uint64_t s_pos[256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63u;
+    const uint64_t i   = (uint64_t)blockIdx.x * blockDim.x + tid;
+    uint64_t       pos = ~0ull;
+    if (i < n) {
+        const uint2 ks = keys[i]; // bin, slot inside the bin
+        pos            = (uint64_t)offsets[ks.x] + chunk[ks.x >> BIN_CHUNK_SHIFT] + ks.y;
+        uint32_t w[Q_RECORD];
 #pragma unroll
-    for (int c = 0; c < Q_COMPONENTS; c++) w[c] = qin.u(c, i);
-    w[14] = w[15] = 0u;
-    uint4* dst = (uint4*)((uint32_t*)qout.base + pos * Q_RECORD);
+        for (int c = 0; c < Q_COMPONENTS; c++) w[c] = qin.u(c, i);
+        w[14] = w[15] = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        for (int k = 0; k < 4; k++) s_rec[tid * 4 + (tid >> 4) + k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+    s_pos[tid] = pos;
+    __syncthreads();
+    // the destination is an AoS queue: one 64-byte record = one line per path
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t r = wbase + 16u * k + (lane >> 2), q = lane & 3u; // record (thread that gathered it), quarter
+        const uint64_t pr = s_pos[r];
+        if (pr != ~0ull) ((uint4*)((uint32_t*)qout.base + pr * Q_RECORD))[q] = s_rec[r * 4 + (r >> 4) + q];
+    }
 }
 
 // RenderPixel's accumulation (renderer.c:98-107): sequential f32 sum over the samples of a pixel, in sample
