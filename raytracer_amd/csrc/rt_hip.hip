@@ -2349,10 +2349,10 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never).  Read per call: the tests switch it.
     const char* sd_env     = getenv("RTX_SORT_DEPTH");
     const int   sort_depth = sd_env ? atoi(sd_env) : 2;
-    // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~4 M rays the closest-hit
+    // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~2.5 M rays the closest-hit
     // pass it speeds up is too short to pay that back (tools/dbg/bands.py: a rank's share under an 8-way split)
     const char*     sm_env  = getenv("RTX_SORT_MIN");
-    const long long bin_min = sm_env ? atoll(sm_env) : (4ll << 20);
+    const long long bin_min = sm_env ? atoll(sm_env) : 2500000ll; // (4 M before the scatter got cheaper)
     static const int sort_every = [] { // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
         const char* e = getenv("RTX_SORT_EVERY");
         return e ? std::max(1, atoi(e)) : 1;
