@@ -353,7 +353,9 @@ def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeyp
         assert np.array_equal(bgr, ref[0]) and same_bits(acc, ref[1]), name
         assert st["rays_at_depth"] == ref[2]["rays_at_depth"] and st["rays_total"] == ref[2]["rays_total"], name
         assert st["hits_shaded"] == ref[2]["hits_shaded"], name
-    assert out["default"][2]["trace_launches"] < ref[2]["trace_launches"] or depth <= 2
+    # (only the cooperative kernels have a TAIL variant: under RTX_TRACE_VARIANT=0..3 every depth stays a pass of its own)
+    if int(os.environ.get("RTX_TRACE_VARIANT", "4")) >= 4:
+        assert out["default"][2]["trace_launches"] < ref[2]["trace_launches"] or depth <= 2
 
 
 @pytest.mark.gpu
