@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 def alg_bytes(vi, vl, vp, vc, rays):
     """Algorithmic bytes of the closest-hit kernel, SURVEY §8(d)'s per-unit figure: 8 B per inner node and per
     leaf visited, (4 B leaf ref + 36 B vertex positions) per primitive test, 64 B ray record read + 44 B hit
-    record write per ray.  The N_* are the kernel's own counters (culled walk: children whose box the ray
+    record write per ray the kernel is handed.  The N_* are the kernel's own counters (culled walk: children whose box the ray
     misses are never fetched; vc only counts them)."""
     return 8 * vi + 8 * vl + 40 * vp + (64 + 44) * rays
 
@@ -147,12 +147,13 @@ def main():
     rays_rank = float(sum(s["rays_total"] for s in stats))
     vals = torch.tensor([dt, rays_rank, sum(s["ms_trace"] for s in stats), float(sum(s["trace_launches"] for s in stats)),
                          float(alg_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["visits_culled"],
-                                         st_count["rays_total"])),
+                                         st_count["rays_total"] - st_count["rays_early_miss"])),
                          float(st_count["rays_total"]), float(st_count["visits_inner"]), float(st_count["visits_leaf"]), float(st_count["visits_prim"]),
                          sum(s["ms_shade"] for s in stats), sum(s["ms_raygen"] for s in stats), sum(s["ms_resolve"] for s in stats),
                          float(st_count["visits_culled"]), sum(s["ms_sort"] for s in stats),
                          float(fetched_bytes(st_count["visits_inner"], st_count["visits_leaf"], st_count["visits_prim"], st_count["visits_culled"],
-                                             st_count["rays_total"]))],
+                                             st_count["rays_total"] - st_count["rays_early_miss"])),
+                         float(st_count["rays_early_miss"])],
                         dtype=torch.float64, device=dev)
     tmax = vals[:1].clone()
     if world > 1:
@@ -185,6 +186,9 @@ def main():
                                       args.height, args.spp, args.depth, args.split),
                        "scene": args.scene, "triangles": int(sc.desc.contents.n_tris), "kd_nodes": int(sc.desc.contents.n_nodes),
                        "rays_per_frame": rays_frame, "rays_per_camera_path": rays_frame / (args.width * args.height * args.spp),
+                       # of rays_per_frame: bounce rays that miss the box of the whole tree and the ground, answered by the shade
+                       # pass that creates them (no record in the closest-hit kernel's queue: not in its algorithmic bytes)
+                       "rays_answered_in_shade": v[15],
                        "visits_per_ray": {"inner": v[6] / rays_frame, "leaf": v[7] / rays_frame, "prim": v[8] / rays_frame,
                                           "children_culled_unfetched": v[12] / rays_frame},
                        "kernel_ms_per_frame": {"trace": ms_trace / args.steps / world, "shade": v[9] / args.steps / world,

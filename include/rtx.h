@@ -184,6 +184,8 @@ typedef struct rtx_stats {
     uint64_t wave_stats[8];
     uint32_t samples_done; /* rtx_render_progressive: samples per pixel in the image when the call returned */
     uint32_t pad_;
+    uint64_t rays_early_miss; /* of rays_total: rays that miss the box of the whole kd-tree and every unbounded object, answered
+                               * (sky) by the shade pass that created them instead of a lane of the closest-hit kernel */
 } rtx_stats;
 
 /* ---- library ---- */

@@ -176,6 +176,7 @@ extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
 #ifndef TAIL_MAX_DEFAULT
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
+#define EARLY_COUNTERS (8 * RTX_MAX_DEPTH) // after the TAIL_COUNTERS: [RTX_MAX_DEPTH * k + d]: rays of depth d answered in the shade pass before
 #define TAIL_COUNTERS 160 // [80 + 8 k]: paths shaded by k_shade, spread over 8 counters; u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
 // body(lo, hi) over [0, n) in contiguous ranges on the host's cores (RTX_HOST_THREADS, default up to 16): the per-node
 // and per-triangle passes of rtx_scene_create.  Results do not depend on the split.
@@ -625,7 +626,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     }
     {
         const uint64_t* c = nullptr;
-        std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64) + TAIL_COUNTERS, 0); // [80 * l ..]: queue count and work counters of lane l; then the tail kernel's
+        std::vector<uint64_t> zeros(RTX_MAX_LANES * (16 + 64) + TAIL_COUNTERS + EARLY_COUNTERS, 0); // [80 * l ..]: queue count and work counters of lane l; then the tail kernel's
         UP(upload(sc, zeros.data(), zeros.size(), &c));
         sc->d_counters = (uint64_t*)c;
     }
@@ -1676,20 +1677,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
 #endif
 DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d);
 DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint32_t& base);
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
+// (waves_per_eu(8): at most 64 VGPRs, so that two 1024-thread blocks share a CU)
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
                                                        unsigned long long* out_count, unsigned long long* shaded_count,
                                                        float* __restrict__ result, uint64_t rcap, int last,
                                                        uint32_t* __restrict__ bin_cnt, uint2* __restrict__ bin_keys, FrameGeom g,
-                                                       uint64_t first_pixel, int first)
+                                                       uint64_t first_pixel, int first, unsigned long long* early_count)
 {
-    __shared__ uint32_t s_wave_cnt[SHADE_BLOCK / 64], s_wave_shaded[SHADE_BLOCK / 64];
+    __shared__ uint32_t s_wave_cnt[SHADE_BLOCK / 64], s_wave_shaded[SHADE_BLOCK / 64], s_wave_early[SHADE_BLOCK / 64];
     __shared__ uint64_t s_base;
     uint64_t  i     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool      alive = false;
     f3        o2 = mk3(0, 0, 0), d2 = mk3(0, 0, 1), T = mk3(0, 0, 0);
     Rng       rng = {0, 0, 0, 0};
     uint32_t  pid = 0;
-    bool      shaded = false;
+    bool      shaded = false, early = false;
     if (i < n) {
         f3         o, d;
         const bool aos = qin.es == Q_RECORD; // binned queue: a 64-byte record per path, read as four 16-byte quarters
@@ -1729,6 +1731,35 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
                 o2    = h.pos;
                 d2    = vnorm(dout); // Ray_Make
                 alive = !last;
+                if (alive && early_count) {
+                    // The next ray's closest-hit query, answered here when it is trivial: a ray that meets the culling
+                    // preconditions and misses the box of everything in the tree (the test the closest-hit kernel makes
+                    // when it loads a ray) and no unbounded object either has no hit — RayColor adds the sky seen along it
+                    // (renderer.c:75) and the path ends, without a queue record, a lane of the closest-hit pass and a
+                    // miss in the next shade pass.  Most rays scattered by the ground leave this way.  Counted as a ray of
+                    // the next depth all the same: it is one Scene_ClosestHit answered, only earlier.
+                    f3 inv2 = vdivc(mk3(1.0f, 1.0f, 1.0f), d2);
+                    const float big = 3.0e38f;
+                    inv2.x = fabsf(inv2.x) > big ? copysignf(big, inv2.x) : inv2.x;
+                    inv2.y = fabsf(inv2.y) > big ? copysignf(big, inv2.y) : inv2.y;
+                    inv2.z = fabsf(inv2.z) > big ? copysignf(big, inv2.z) : inv2.z;
+                    const float rx = o2.x - S.cull_c[0], ry = o2.y - S.cull_c[1], rz = o2.z - S.cull_c[2];
+                    const float r2 = rx * rx + ry * ry + rz * rz, dd = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
+                    if (r2 <= S.cull_ro2 && fabsf(dd - 1.0f) <= 1.0e-3f && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o2, inv2, RTX_INF)) {
+                        bool plane = false;
+                        for (uint32_t k = 0; k < S.n_planes; k++) {
+                            const float* pl = S.plane + 8ull * k;
+                            float        tp;
+                            plane = plane || Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o2, d2, RT_EPSILON, RTX_INF, tp);
+                        }
+                        if (!plane) {
+                            const f3 L = vmulc(T, Skybox_ColorAt(S, d2));
+                            result[0 * rcap + pid] = L.x, result[1 * rcap + pid] = L.y, result[2 * rcap + pid] = L.z;
+                            alive = false;
+                            early = true;
+                        }
+                    }
+                }
                 if (last) {
                     // depth exhausted: RayColor(depth 0) is black (renderer.c:56-58) and the path returns
                     // surface * black — zero, or NaN where a lobe produced an inf/NaN surface colour; the
@@ -1747,12 +1778,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(SceneDev S, Queue qin, Hi
     const unsigned long long mask = __ballot(alive);
     const uint32_t wcnt = __popcll(mask);
     const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-    const unsigned long long smask = __ballot(shaded);
-    if (lane == 0) s_wave_cnt[wave] = wcnt, s_wave_shaded[wave] = (uint32_t)__popcll(smask);
+    const unsigned long long smask = __ballot(shaded), emask = __ballot(early);
+    if (lane == 0) s_wave_cnt[wave] = wcnt, s_wave_shaded[wave] = (uint32_t)__popcll(smask), s_wave_early[wave] = (uint32_t)__popcll(emask);
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t total = 0, sh = 0;
-        for (uint32_t w = 0; w < SHADE_BLOCK / 64; w++) total += s_wave_cnt[w], sh += s_wave_shaded[w];
+        uint32_t total = 0, sh = 0, ea = 0;
+        for (uint32_t w = 0; w < SHADE_BLOCK / 64; w++) total += s_wave_cnt[w], sh += s_wave_shaded[w], ea += s_wave_early[w];
+        if (ea) atomicAdd(early_count + RTX_MAX_DEPTH * (blockIdx.x & 7u), (unsigned long long)ea); // 8 counters per depth
         s_base = total ? atomicAdd(out_count, (unsigned long long)total) : 0ull;
         if (sh) atomicAdd(shaded_count + 8 * (blockIdx.x & 7u), (unsigned long long)sh); // statistics only: 8 counters, 64 bytes apart
     }
@@ -2379,7 +2411,12 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
     // RTX_RAYGEN_LEAN=0: k_raygen stores whole path records and the first shade pass reads them (the tests compare the two)
     const char*         lr_env      = getenv("RTX_RAYGEN_LEAN");
     const bool          lean_raygen = !lr_env || atoi(lr_env) != 0;
-    HIPCHECK(hipMemsetAsync(d_tail, 0, TAIL_COUNTERS * sizeof(uint64_t), st));
+    HIPCHECK(hipMemsetAsync(d_tail, 0, (TAIL_COUNTERS + EARLY_COUNTERS) * sizeof(uint64_t), st));
+    // rays that miss the box of the whole tree and every unbounded object are answered by the shade pass that creates
+    // them (see k_shade); not under the literal walk, which is there to walk, nor when asked not to (the tests compare)
+    unsigned long long* d_early   = d_tail + TAIL_COUNTERS;
+    const char*         em_env    = getenv("RTX_EARLY_MISS");
+    const bool          early_miss = !literal && (!em_env || atoi(em_env) != 0);
 
     int        nev = 0;
     hipEvent_t evA, evB;
@@ -2458,7 +2495,8 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         if (a.bin) HIPCHECK(hipMemsetAsync(a.bin_cnt, 0, bin_bytes, a.s));
         r = timed(2, depth, a.s, [&] {
             hipLaunchKernelGGL(k_shade, dim3(blocks_for(a.n, SHADE_BLOCK)), dim3(SHADE_BLOCK), 0, a.s, sc->dev, a.qin, a.hits, a.n, soa(a, a.cur ^ 1), a.d_cnt,
-                               d_shaded, a.result, cap, a.last ? 1 : 0, a.bin ? a.bin_cnt : nullptr, a.bin_keys, a.gs, a.px0, depth == 0 && lean_raygen ? 1 : 0);
+                               d_shaded, a.result, cap, a.last ? 1 : 0, a.bin ? a.bin_cnt : nullptr, a.bin_keys, a.gs, a.px0, depth == 0 && lean_raygen ? 1 : 0,
+                               early_miss && !a.last ? d_early + depth + 1 : nullptr);
         });
         if (r != RTX_OK) return r;
         *a.h_alive = 0;
@@ -2572,6 +2610,15 @@ extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx
         for (int i = 0; i < RTX_MAX_DEPTH; i++) local.rays_at_depth[i] += tc[i], local.rays_total += tc[i];
         local.hits_shaded += tc[RTX_MAX_DEPTH];
     }
+    if (early_miss) {
+        uint64_t ec[EARLY_COUNTERS];
+        HIPCHECK(hipMemcpy(ec, d_early, sizeof ec, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++)
+            for (int dpt = 0; dpt < RTX_MAX_DEPTH; dpt++) {
+                const uint64_t c = ec[RTX_MAX_DEPTH * k + dpt];
+                local.rays_at_depth[dpt] += c, local.rays_total += c, local.rays_early_miss += c;
+            }
+    }
     local.samples_done = g.n_samples;
     if (stats) *stats = local;
     return RTX_OK;
@@ -2589,7 +2636,7 @@ extern "C" int rtx_resolve_device(rtx_scene* sc, const float* d_accum, uint32_t 
 
 static void add_stats(rtx_stats& t, const rtx_stats& s)
 {
-    t.rays_total += s.rays_total, t.camera_paths += s.camera_paths, t.hits_shaded += s.hits_shaded;
+    t.rays_total += s.rays_total, t.camera_paths += s.camera_paths, t.hits_shaded += s.hits_shaded, t.rays_early_miss += s.rays_early_miss;
     t.visits_inner += s.visits_inner, t.visits_leaf += s.visits_leaf, t.visits_prim += s.visits_prim, t.visits_culled += s.visits_culled;
     t.ms_total += s.ms_total, t.ms_trace += s.ms_trace, t.ms_shade += s.ms_shade, t.ms_raygen += s.ms_raygen, t.ms_resolve += s.ms_resolve;
     t.ms_sort += s.ms_sort, t.trace_launches += s.trace_launches, t.passes += s.passes;

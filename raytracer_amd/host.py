@@ -147,7 +147,7 @@ class rtx_stats(C.Structure):
         ("ms_raygen", C.c_double), ("ms_resolve", C.c_double), ("trace_launches", C.c_uint32), ("passes", C.c_uint32),
         ("ms_trace_at_depth", C.c_double * RTX_MAX_DEPTH),
         ("visits_culled", C.c_uint64), ("ms_sort", C.c_double), ("wave_stats", C.c_uint64 * 8),
-        ("samples_done", C.c_uint32), ("pad_", C.c_uint32),
+        ("samples_done", C.c_uint32), ("pad_", C.c_uint32), ("rays_early_miss", C.c_uint64),
     ]
 
 

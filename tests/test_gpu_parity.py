@@ -461,3 +461,28 @@ def test_awkward_rays_match_the_oracle(built_scenes, device_scenes, scene):
         fin = ok & np.isfinite(want["position"]).all(axis=1) & np.isfinite(want["normal"]).all(axis=1)
         assert same_bits(g["position"][fin], want["position"][fin]) and same_bits(g["normal"][fin], want["normal"][fin])
     assert (want["prim_id"] != 0xFFFFFFFF).mean() > 0.2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,depth", [("dragon1", 240, 135, 8, 8), ("materials", 320, 180, 8, 6), ("teapot", 200, 100, 4, 3), ("pear", 160, 90, 4, 5)])
+def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_scenes, monkeypatch, scene, w, h, spp, depth):
+    """A bounce ray that misses the box of the whole kd-tree and every unbounded object is answered (sky) by the shade
+    pass that creates it instead of going through the queue, the closest-hit kernel and the next shade pass.  Frame,
+    rays per depth (such a ray still counts: it is one Scene_ClosestHit answered) and shaded hits are those of the
+    frame with every ray traced (RTX_EARLY_MISS=0), bit for bit — with per-depth passes and with the tail launch."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    p = hip.make_params(w, h, spp, depth, seed=(13, 14))
+    out = {}
+    for name, env in (("traced", {"RTX_EARLY_MISS": "0"}), ("early", {}), ("early_passes", {"RTX_TAIL_MAX": "0"}), ("traced_passes", {"RTX_EARLY_MISS": "0", "RTX_TAIL_MAX": "0"})):
+        for k in ("RTX_EARLY_MISS", "RTX_TAIL_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[name] = ds.render(sc.rtx_camera(), p)
+    ref = out["traced"]
+    for name, (bgr, acc, st) in out.items():
+        assert np.array_equal(bgr, ref[0]) and same_bits(acc, ref[1]), name
+        assert st["rays_at_depth"] == ref[2]["rays_at_depth"] and st["rays_total"] == ref[2]["rays_total"] and st["hits_shaded"] == ref[2]["hits_shaded"], name
+    assert ref[2]["rays_early_miss"] == 0 and out["traced_passes"][2]["rays_early_miss"] == 0
+    if scene in ("dragon1", "teapot"):  # open scenes on a ground plane: a good part of the bounce rays leaves at once
+        assert out["early"][2]["rays_early_miss"] > 0.1 * ref[2]["rays_total"]
