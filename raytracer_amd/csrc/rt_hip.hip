@@ -1745,7 +1745,15 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(8))
                     inv2.z = fabsf(inv2.z) > big ? copysignf(big, inv2.z) : inv2.z;
                     const float rx = o2.x - S.cull_c[0], ry = o2.y - S.cull_c[1], rz = o2.z - S.cull_c[2];
                     const float r2 = rx * rx + ry * ry + rz * rz, dd = d2.x * d2.x + d2.y * d2.y + d2.z * d2.z;
-                    if (r2 <= S.cull_ro2 && fabsf(dd - 1.0f) <= 1.0e-3f && box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o2, inv2, RTX_INF)) {
+                    bool none = r2 <= S.cull_ro2 && fabsf(dd - 1.0f) <= 1.0e-3f;
+                    if (none && !box_missed(S, S.root_q[0], S.root_q[1], S.root_q[2], o2, inv2, RTX_INF)) {
+                        // inside the root's box, but perhaps outside both of its children's (the first split of these
+                        // scenes has the model on one side and the light on the other): the closest-hit kernel's first
+                        // step would then find nothing to descend into and nothing to push, whatever tMax it tests with
+                        const uint4 qa = S.nodes32[2ull * S.root], qb = S.nodes32[2ull * S.root + 1];
+                        none = (qa.y >> 30) != 3u && box_missed(S, qa.z, qa.w, qb.x, o2, inv2, RTX_INF) && box_missed(S, qb.y, qb.z, qb.w, o2, inv2, RTX_INF);
+                    }
+                    if (none) {
                         bool plane = false;
                         for (uint32_t k = 0; k < S.n_planes; k++) {
                             const float* pl = S.plane + 8ull * k;
