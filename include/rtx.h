@@ -219,6 +219,21 @@ int rtx_trace_closest(rtx_scene* scene, size_t n, const float* origin_xyz, const
 int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, uint32_t* d_hits,
                              void* stream, uint32_t flags, uint64_t* d_visit_counters /* 4 x u64: inner, leaf, prim, culled */);
 
+/* ---- the same query for callers that CANNOT ALLOCATE.  No counterpart in the reference: it is there for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  rtx_trace_closest with DEVICE
+ * pointers in the same interleaved layouts (origin / dir / position / normal: xyz; uv: 2 floats; outputs may be
+ * NULL), asynchronous on `stream`; it calls no hipMalloc / hipFree or other allocating routine, only kernel
+ * launches and one hipMemsetAsync.  The staging rtx_trace_closest allocates per call (the SoA ray queue, the
+ * kernel's hit records, its work counters: 40 bytes per ray + 512) lives in a static device array of
+ * RTX_NOALLOC_MAX_RAYS rays (10 MB) that every GPU the library runs on holds until the process ends; a batch
+ * beyond that is refused with RTX_E_LIMIT.  All calls on one GPU — whatever the scene or the stream — share that
+ * GPU's array: calls that overlap on one GPU race; serialise them (one stream, or events).  RTX_TRACE_UNIT_DIR
+ * and RTX_TRACE_LITERAL as above; RTX_RENDER_COUNT_VISITS is refused. ---- */
+#define RTX_NOALLOC_MAX_RAYS (1u << 18)
+int rtx_closest_hit_noalloc(rtx_scene* scene, size_t n, const float* d_origin_xyz, const float* d_dir_xyz,
+                            uint32_t* d_prim_id, float* d_t, float* d_position_xyz, float* d_normal_xyz, float* d_uv,
+                            uint8_t* d_front_face, void* stream, uint32_t flags);
+
 /* ---- frame-level seam: replaces Render_Worker/RenderTile/RenderPixel/RayColor
  *      (src/rt/renderer.c:54-178).  Blocking.  bgr_out = ImageRGB.pix (RGB{b,g,r},
  *      src/gfx/color.h:19-23; row 0 = bottom scanline), width*height*3 bytes, host memory, may be

@@ -98,6 +98,7 @@ struct rtx_scene {
     hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
     unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
+    unsigned char* noalloc_scratch; // this device's copy of the static scratch array of rtx_closest_hit_noalloc (hipGetSymbolAddress, at create)
     unsigned persist_blocks[10]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)], [8 + variant - 4]: tail (0 = not queried yet)
 };
 
@@ -465,6 +466,8 @@ extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint16_t* qbox6, flo
     return RTX_OK;
 }
 
+static int noalloc_scratch_address(rtx_scene* sc);
+
 extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene** out)
 {
     if (!out) return fail(RTX_E_INVALID, "null output");
@@ -484,6 +487,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     sc->ws        = nullptr;
     sc->ws_bytes  = 0;
     sc->ev_fork = nullptr, sc->h_alive = nullptr;
+    sc->noalloc_scratch = nullptr;
     for (int i = 0; i < RTX_MAX_LANES - 1; i++) sc->aux_stream[i] = nullptr, sc->ev_join[i] = nullptr;
     memset(sc->persist_blocks, 0, sizeof sc->persist_blocks);
     memset(&sc->dev, 0, sizeof sc->dev);
@@ -630,11 +634,12 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         UP(upload(sc, zeros.data(), zeros.size(), &c));
         sc->d_counters = (uint64_t*)c;
     }
-#undef UP
     tm.lap("the rest");
     S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
     S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root = d->root_index;
     for (int i = 0; i < 6; i++) S.skybox_tex[i] = d->skybox_tex[i];
+    UP(noalloc_scratch_address(sc)); // needs cull_useful (set above) to know which kernels this scene launches
+#undef UP
     *out = sc;
     return RTX_OK;
 }
@@ -2141,16 +2146,59 @@ static bool tail_capable(const rtx_scene* sc, bool literal)
     return variant >= 4;
 }
 
+// persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
+// that would not fit simply start later and find the queue empty — nothing waits on another block)
+typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t,
+                              TailArgs);
+struct TraceKernel {
+    int           variant;
+    PersistKernel kern; // null: variant 0, one ray per thread
+    int           slot, bs;
+};
+// default: the culled walk where its boxes help, else the literal one; RTX_TRACE_VARIANT overrides
+static TraceKernel pick_trace_kernel(const rtx_scene* sc, bool count, bool literal, bool tail)
+{
+    const int  tv      = trace_variant();
+    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
+    TraceKernel k;
+    k.variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
+    const int variant = k.variant;
+    k.kern = variant == 0   ? nullptr
+             : variant == 1 ? (count ? k_trace_persist<true> : k_trace_persist<false>)
+             : variant == 2 ? (count ? k_trace_flat<true, false, false> : k_trace_flat<false, false, false>)
+             : variant == 3 ? (count ? k_trace_flat<true, true, false> : k_trace_flat<false, true, false>)
+             : variant == 4 ? (count ? k_trace_flat<true, true, true> : k_trace_flat<false, true, true>)
+                            : (count ? k_trace_flat<true, false, true> : k_trace_flat<false, false, true>);
+    if (tail && variant >= 4) k.kern = variant == 4 ? k_trace_flat<false, true, true, true> : k_trace_flat<false, false, true, true>;
+    k.slot = tail ? 8 + (variant - 4) : (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
+    k.bs   = variant == 1 ? 256 : TRACE_BLOCK;
+    return k;
+}
+// resident grid of a persistent kernel on the scene's device: queried once per kernel and scene, then cached
+static int resident_blocks(rtx_scene* sc, const TraceKernel& k, unsigned* out)
+{
+    if (sc->persist_blocks[k.slot] == 0) {
+        int per_cu = 0, cus = 0;
+        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.kern, k.bs, 0));
+        HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
+        const int wpb = k.bs / 64; // RTX_TRACE_BLOCKS_PER_CU counts groups of 4 waves (one per SIMD), whatever the block size
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu * wpb > 32) per_cu = 32 / wpb;
+        if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e) * 4 / wpb)); // experiments
+        sc->persist_blocks[k.slot] = (unsigned)(per_cu * cus);
+    }
+    *out = sc->persist_blocks[k.slot];
+    return RTX_OK;
+}
+
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
                         bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false,
                         const TailArgs* tail = nullptr)
 {
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
-    // default: the culled walk where its boxes help, else the literal one; RTX_TRACE_VARIANT overrides
-    const int  tv      = trace_variant();
-    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
-    const int  variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
+    const TraceKernel tk      = pick_trace_kernel(sc, count, literal, tail != nullptr);
+    const int         variant = tk.variant;
     if (variant == 0) {
         unsigned nb = blocks_for(n, 64);
         if (count) {
@@ -2161,40 +2209,21 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
         HIPCHECK(hipGetLastError());
         return RTX_OK;
     }
-    // persistent waves: a grid that is fully resident (blocks per CU from the occupancy query; blocks
-    // that would not fit simply start later and find the queue empty — nothing waits on another block)
-    typedef void (*PersistKernel)(SceneDev, const float*, uint64_t, uint64_t, uint32_t*, uint64_t, unsigned long long*, uint32_t, uint64_t*, uint32_t,
-                                  TailArgs);
     if (tail && (variant < 4 || count)) return fail(RTX_E_INVALID, "no tail variant of this closest-hit kernel");
-    static const uint32_t tune = [tv] { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes); read once
+    static const uint32_t tune = [] { // RTX_TRACE_TUNE = leaf_min,inner_min,refill_min (lanes); read once
         unsigned    a = 16, b = 8, c = REFILL_MIN;
-        if (tv >= 4) a = 4; // cooperative leaves fill their 64 slots from few lanes
+        if (trace_variant() >= 4) a = 4; // cooperative leaves fill their 64 slots from few lanes
         const char* e = getenv("RTX_TRACE_TUNE");
         if (e) sscanf(e, "%u,%u,%u", &a, &b, &c);
         a = std::min(std::max(a, 1u), 64u), b = std::min(std::max(b, 1u), 64u), c = std::min(std::max(c, 1u), 64u);
         return a | b << 8 | c << 16;
     }();
-    PersistKernel kern    = variant == 1   ? (count ? k_trace_persist<true> : k_trace_persist<false>)
-                            : variant == 2 ? (count ? k_trace_flat<true, false, false> : k_trace_flat<false, false, false>)
-                            : variant == 3 ? (count ? k_trace_flat<true, true, false> : k_trace_flat<false, true, false>)
-                            : variant == 4 ? (count ? k_trace_flat<true, true, true> : k_trace_flat<false, true, true>)
-                                           : (count ? k_trace_flat<true, false, true> : k_trace_flat<false, false, true>);
-    if (tail) kern = variant == 4 ? k_trace_flat<false, true, true, true> : k_trace_flat<false, false, true, true>;
-    const int     slot    = tail ? 8 + (variant - 4) : (count ? 1 : 0) + 2 * (variant <= 2 ? 0 : variant - 2);
-    const int     bs      = variant == 1 ? 256 : TRACE_BLOCK;
-    if (sc->persist_blocks[slot] == 0) {
-        int per_cu = 0, cus = 0;
-        HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, bs, 0));
-        HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, sc->device));
-        const int wpb = bs / 64; // RTX_TRACE_BLOCKS_PER_CU counts groups of 4 waves (one per SIMD), whatever the block size
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu * wpb > 32) per_cu = 32 / wpb;
-        if (const char* e = getenv("RTX_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e) * 4 / wpb)); // experiments
-        sc->persist_blocks[slot] = (unsigned)(per_cu * cus);
-    }
+    const int bs       = tk.bs;
+    unsigned  resident = 0;
+    int       rc       = resident_blocks(sc, tk, &resident);
+    if (rc != RTX_OK) return rc;
     if (!work) work = (unsigned long long*)&sc->d_counters[16]; // 8 part counters, 64 B apart
     HIPCHECK(hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), st));
-    const unsigned resident = sc->persist_blocks[slot];
     // grab size: 160 rays on the big coherent queues (fewer atomics, neighbouring rays stay on one wave), one wave's worth
     // on the smaller ones, where balance at the end of the launch is worth more (sweep: tools/dbg, RTX_TRACE_CHUNK)
     uint64_t chunk = n >= (64ull << 20) ? 160 : 64;
@@ -2203,7 +2232,7 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     TailArgs ta;
     memset(&ta, 0, sizeof ta);
     if (tail) ta = *tail;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
+    hipLaunchKernelGGL(tk.kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
                        tune | (bounce_rays && !count ? 1u << 25 : 0u), ta);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
@@ -2283,6 +2312,67 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
             stats->visits_inner = c[0], stats->visits_leaf = c[1], stats->visits_prim = c[2], stats->visits_culled = c[3];
         }
     }
+    return RTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rtx_closest_hit_noalloc — rtx_trace_closest for callers that cannot allocate (rtx.h).  What rtx_trace_closest keeps in
+// hipMalloc'ed staging buffers — the SoA ray queue k_prep_rays writes and the closest-hit kernel reads, the kernel's
+// hit records, its work-grab counters — lives in ONE static device array, `scratch`, that every GPU the library runs on
+// holds from load to exit.  In host code the array's NAME is not a device address: rtx_scene_create asks
+// hipGetSymbolAddress for this device's copy once, with the device current, and everything below uses that pointer.
+// ---------------------------------------------------------------------------------------------
+struct NoAllocScratch {
+    float              rays[6 * RTX_NOALLOC_MAX_RAYS]; // ox oy oz dx dy dz, component stride = n of the call
+    uint32_t           hits[4 * RTX_NOALLOC_MAX_RAYS]; // ref t u v, component stride = n of the call
+    unsigned long long work[64];                       // the persistent kernel's 8 part counters, 64 bytes apart
+};
+// (no __attribute__((used)) here: clang then keeps the symbol LOCAL in the code object and the runtime cannot find it;
+// the host-side use below is what makes it externalise the static)
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+static int noalloc_scratch_address(rtx_scene* sc) // rtx_scene_create, device current
+{
+    void* ptr = nullptr;
+    HIPCHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RTX_E_HIP, "hipGetSymbolAddress returned no address for the scratch array");
+    sc->noalloc_scratch = (unsigned char*)ptr;
+    // the resident grids of the two closest-hit kernels the entry point may launch are queried here as well, so that
+    // the entry point itself makes nothing but stream operations
+    for (int literal = 0; literal < 2; literal++) {
+        const TraceKernel tk = pick_trace_kernel(sc, false, literal != 0, false);
+        unsigned          nb;
+        if (tk.kern) {
+            int rc = resident_blocks(sc, tk, &nb);
+            if (rc != RTX_OK) return rc;
+        }
+    }
+    return RTX_OK;
+}
+
+extern "C" int rtx_closest_hit_noalloc(rtx_scene* sc, size_t n, const float* d_origin_xyz, const float* d_dir_xyz, uint32_t* d_prim_id, float* d_t,
+                                       float* d_position_xyz, float* d_normal_xyz, float* d_uv, uint8_t* d_front_face, void* stream, uint32_t flags)
+{
+    if (!sc || (n && (!d_origin_xyz || !d_dir_xyz))) return fail(RTX_E_INVALID, "null argument");
+    if (n > RTX_NOALLOC_MAX_RAYS)
+        return fail(RTX_E_LIMIT, "rtx_closest_hit_noalloc: %zu rays exceed the scratch array's %u (RTX_NOALLOC_MAX_RAYS); split the batch", n,
+                    (unsigned)RTX_NOALLOC_MAX_RAYS);
+    if (flags & RTX_RENDER_COUNT_VISITS) return fail(RTX_E_INVALID, "rtx_closest_hit_noalloc has no visit counters: use rtx_trace_closest");
+    if (!sc->noalloc_scratch) return fail(RTX_E_HIP, "the scratch array has no address on this device");
+    if (n == 0) return RTX_OK;
+    HIPCHECK(hipSetDevice(sc->device));
+    hipStream_t     st = (hipStream_t)stream;
+    NoAllocScratch* sx = (NoAllocScratch*)sc->noalloc_scratch; // device address: only ever handed to kernels and hipMemsetAsync
+    // every ray of the batch overwrites its own slots of rays[] and hits[] (stride n), and launch_trace clears the
+    // work counters: nothing of the previous call is read
+    hipLaunchKernelGGL(k_prep_rays, dim3(blocks_for(n, 256)), dim3(256), 0, st, d_origin_xyz, d_dir_xyz, (uint64_t)n, sx->rays,
+                       (flags & RTX_TRACE_UNIT_DIR) ? 1 : 0);
+    HIPCHECK(hipGetLastError());
+    int rc = launch_trace(sc, sx->rays, n, n, sx->hits, n, st, false, nullptr, (flags & RTX_TRACE_LITERAL) != 0, sx->work);
+    if (rc != RTX_OK) return rc;
+    hipLaunchKernelGGL(k_expand_hits, dim3(blocks_for(n, 256)), dim3(256), 0, st, sc->dev, sx->rays, sx->hits, (uint64_t)n, d_prim_id, d_t, d_position_xyz,
+                       d_normal_xyz, d_uv, d_front_face);
+    HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
 

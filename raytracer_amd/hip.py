@@ -19,7 +19,8 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc"]
+RTX_NOALLOC_MAX_RAYS = 1 << 18
 
 _lib = None
 
@@ -55,6 +56,7 @@ def lib() -> C.CDLL:
     sig("rtx_trace_closest", C.c_int, vp, C.c_size_t, f32p, f32p, u32p, f32p, f32p, f32p, f32p, u8p,
         C.POINTER(rtx_stats), C.c_uint32)
     sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
+    sig("rtx_closest_hit_noalloc", C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32)
     sig("rtx_render", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), u8p, f32p,
         C.POINTER(rtx_stats))
     sig("rtx_render_progressive", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_uint32, u8p, f32p,
@@ -228,6 +230,11 @@ class DeviceScene:
     def trace_closest_device(self, n, d_rays_ptr, d_hits_ptr, stream=0, flags=0, d_counters_ptr=0):
         _check(lib().rtx_trace_closest_device(self.handle, n, C.c_void_p(d_rays_ptr), C.c_void_p(d_hits_ptr),
                                               C.c_void_p(stream), flags, C.c_void_p(d_counters_ptr)))
+
+    def closest_hit_noalloc(self, n, d_origin, d_dir, d_prim_id=0, d_t=0, d_position=0, d_normal=0, d_uv=0, d_front=0, stream=0, flags=0):
+        """rtx_closest_hit_noalloc: device pointers (ints) in rtx_trace_closest's layouts; asynchronous on `stream`."""
+        _check(lib().rtx_closest_hit_noalloc(self.handle, n, *(C.c_void_p(x) for x in (d_origin, d_dir, d_prim_id, d_t, d_position, d_normal, d_uv,
+                                                                                        d_front, stream)), flags))
 
     # ---- unit seams ----
     def camera_rays(self, cam, params, pixel_index, sample):
