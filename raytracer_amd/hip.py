@@ -38,6 +38,17 @@ def lib() -> C.CDLL:
     path = os.path.join(LIB_DIR, "librt_hip.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension was not built (python -m raytracer_amd.build)")
+    # ONE HIP runtime per process.  PyTorch's wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) and
+    # libhsa-runtime64.so; librt_hip.so needs libamdhip64.so.7.  If torch is loaded first, librt_hip.so binds to the
+    # runtime already in the process.  The other way round /opt/rocm's runtime comes in first and a later `import torch`
+    # starts a SECOND one, which finds no GPU (the driver gives a process's GPU VM to one runtime: "No HIP GPUs are
+    # available").  Callers that share device memory with torch (bench.py, the multi-GPU path, the tests) therefore need
+    # torch first — done here, so that the order of imports in user code does not matter.  RTX_NO_TORCH_PRELOAD=1 skips it.
+    if os.environ.get("RTX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     vp, u32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
 

@@ -112,17 +112,50 @@ def g_trace():
         save("trace_%s.npz" % sc, rays=rays, rec=np.fromfile(fo, HITREC))
 
 
-def g_render():
-    for sc, w, h, spp, depth in [("teapot", 96, 54, 8, 8), ("bunny", 96, 54, 8, 8), ("dragon1", 96, 54, 8, 8),
-                                 ("pear", 96, 54, 8, 16), ("materials", 128, 72, 16, 8), ("materials", 64, 36, 4, 1)]:
-        f = os.path.join(TMP, "r.bin")
-        meta = ref(sc, "render", w, h, spp, depth, 1, 2, 8, f)
-        raw = open(f, "rb").read()
-        cum = np.frombuffer(raw, "<f4", w * h * 3, 16).reshape(h, w, 3)
-        bgr = np.frombuffer(raw, np.uint8, w * h * 3, 16 + w * h * 12).reshape(h, w, 3)
-        save("render_%s_%dx%d_%dspp_d%d.npz" % (sc, w, h, spp, depth), cum=cum, bgr=bgr,
-             meta=np.array([w, h, spp, depth, 1, 2], np.int64))
+def ref_render(sc, w, h, spp, depth, lo, hi):
+    f = os.path.join(TMP, "r.bin")
+    meta = ref(sc, "render", w, h, spp, depth, lo, hi, 8, f)
+    raw = open(f, "rb").read()
+    cum = np.frombuffer(raw, "<f4", w * h * 3, 16).reshape(h, w, 3)
+    bgr = np.frombuffer(raw, np.uint8, w * h * 3, 16 + w * h * 12).reshape(h, w, 3)
+    return cum, bgr, meta
+
+
+RENDERS = [("teapot", 96, 54, 8, 8), ("bunny", 96, 54, 8, 8), ("dragon1", 96, 54, 8, 8), ("pear", 96, 54, 8, 16),
+           ("materials", 128, 72, 16, 8), ("materials", 64, 36, 4, 1),
+           # the bench configuration's sampling (BASELINE configs[2]: 64 spp, depth 8) and config 5's (1024 spp)
+           ("dragon1", 240, 135, 64, 8), ("dragon1", 192, 108, 1024, 8)]
+
+
+def g_render(only=None):
+    for sc, w, h, spp, depth in RENDERS:
+        name = "render_%s_%dx%d_%dspp_d%d.npz" % (sc, w, h, spp, depth)
+        if only and only not in name:
+            continue
+        cum, bgr, meta = ref_render(sc, w, h, spp, depth, 1, 2)
+        save(name, cum=cum, bgr=bgr, meta=np.array([w, h, spp, depth, 1, 2], np.int64))
         print(meta)
+
+
+def g_noise():
+    """CPU-vs-CPU noise floor: the reference against ITSELF with another seed, same scene and sampling.
+    Two frames that agree path for path differ by far less than this; two frames that are merely both correct
+    differ by about this much.  The numbers go to noise.json; the GPU tests' image bounds cite them."""
+    out = {}
+    for sc, w, h, spp, depth in [("dragon1", 240, 135, 64, 8), ("dragon1", 96, 54, 8, 8), ("materials", 128, 72, 16, 8), ("bunny", 96, 54, 8, 8),
+                                 ("teapot", 96, 54, 8, 8), ("pear", 96, 54, 8, 16)]:
+        a_cum, a_bgr, _ = ref_render(sc, w, h, spp, depth, 1, 2)
+        b_cum, b_bgr, _ = ref_render(sc, w, h, spp, depth, 3, 4)
+        fin = np.isfinite(a_cum).all(axis=2) & np.isfinite(b_cum).all(axis=2)
+        d8 = a_bgr[fin].astype(np.float64) - b_bgr[fin].astype(np.float64)
+        rmse8 = float(np.sqrt(np.mean(d8 ** 2)))
+        dl = (a_cum[fin].astype(np.float64) - b_cum[fin].astype(np.float64)) / spp
+        out["%s_%dx%d_%dspp_d%d" % (sc, w, h, spp, depth)] = {
+            "seeds": [[1, 2], [3, 4]], "rmse_8bit": rmse8, "psnr_8bit_db": float(10 * np.log10(255.0 ** 2 / rmse8 ** 2)),
+            "rmse_linear_mean": float(np.sqrt(np.mean(dl ** 2))), "finite_pixels": int(fin.sum()), "pixels": int(fin.size)}
+        print(sc, out["%s_%dx%d_%dspp_d%d" % (sc, w, h, spp, depth)])
+    json.dump(out, open(os.path.join(HERE, "noise.json"), "w"), indent=1)
+    print("wrote noise.json")
 
 
 def g_bounce():
@@ -169,10 +202,13 @@ def g_sky():
         save("sky_%s.npz" % sc, dirs=d, rgb=np.fromfile(fo, "<f4").reshape(-1, 3))
 
 
-GROUPS = dict(rng=g_rng, kd=g_kd, primary=g_primary, trace=g_trace, render=g_render, bounce=g_bounce, sky=g_sky)
+GROUPS = dict(rng=g_rng, kd=g_kd, primary=g_primary, trace=g_trace, render=g_render, bounce=g_bounce, sky=g_sky, noise=g_noise)
 
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_parity is missing: make -C oracle ref (needs /root/reference)")
     for g in (sys.argv[1:] or list(GROUPS)):
-        GROUPS[g]()
+        if g.startswith("render:"):  # render:<substring of the fixture's name>
+            g_render(g[7:])
+        else:
+            GROUPS[g]()

@@ -4,8 +4,9 @@ real reference and against the CPU oracle on the same seeded inputs.
 Bars (BASELINE.json north_star / SURVEY §7):
   * primary-ray hit primitive ids: bit-exact;  t / position / normal / uv: <= 2 ulp (observed 0)
   * RNG, camera rays: bit-exact (integer RNG, un-contracted f32 camera arithmetic)
-  * single material bounces: |delta| <= 1e-5 relative (device sinf/cosf/powf vs glibc)
-  * seeded renders at matched spp: PSNR >= 30 dB on the 8-bit image (observed far higher)
+  * single material bounces: every decision and RNG draw count equal, |delta| <= 1e-5 relative (device sinf/cosf/powf vs glibc)
+  * seeded renders at matched spp: RMSE <= the reference's own different-seed RMSE + 10 % (tests/golden/noise.json)
+    and, seeds matched, <= 1 % of it; non-finite pixels in the same places; see _check_frame_vs_reference
 """
 import json
 import os
@@ -125,32 +126,36 @@ def test_culled_walk_replays_on_the_cpu(built_scenes, device_scenes, scene):
 
 
 def test_material_bounce_vs_reference(built_scenes, device_scenes):
+    """Material_Bounce (object.c:64-143) for 96 records of each of the 11 material kinds against the reference's own
+    outputs.  Every decision is the reference's on every record — continue / stop, the lobe chosen, reflect
+    or refract: the bool returned and the RNG state left behind (= the number of draws taken) are EQUAL, no exemptions —
+    and the colours are within 1e-5 relative (device sinf/cosf/powf against glibc's; measured worst 3.1e-6,
+    tools/dbg/measure_parity.py), the outgoing unit direction within 1e-5 of its length (measured 1.1e-6).  Non-finite
+    values (some Disney lobes divide by zero at grazing incidence, in the reference too) must be non-finite on both sides."""
     g = golden("bounce_materials.npz")
     inp, out, names = g["inp"], g["out"], [str(x) for x in g["names"]]
     sc, ds = built_scenes("materials"), device_scenes("materials")
-    worst = 0.0
+    assert len(names) == 11
     for mi, name in enumerate(names):
         a, want = inp[inp["mat"] == mi], out[inp["mat"] == mi]
         state = np.array([O.rng_state_after_seed(int(lo), int(hi)) for lo, hi in zip(a["seed_lo"], a["seed_hi"])], np.uint32)
         got = ds.material_bounce(sc.material_index(name), a["dir"], a["pos"], a["n"], a["uv"], a["front"].astype(np.uint8), state)
         ref = O.material_bounce(sc.desc, sc.material_index(name), a["dir"], a["pos"], a["n"], a["uv"], a["front"].astype(np.uint8), state)
-        # decisions (reflect/refract, lobe choice, absorbed) may flip only where a libm ulp decides; require >= 97 %
-        same = got["cont"] == want["cont"].astype(np.uint8)
-        assert same.mean() >= 0.97, name
-        assert np.array_equal(got["rng_state"][same], ref["rng_state"][same]) or name in ("m2", "m7", "m10"), name
+        assert np.array_equal(got["cont"], want["cont"].astype(np.uint8)), name
+        assert np.array_equal(got["rng_state"], ref["rng_state"]), name  # the oracle's state is pinned to the reference's next draws (test_oracle_pinned)
         for k, r in [("surface", "surf"), ("emitted", "emit")]:
-            x, y = got[k][same], want[r][same]
-            fin = np.isfinite(y).all(axis=1) & np.isfinite(x).all(axis=1)
+            x, y = got[k], want[r]
+            assert np.array_equal(np.isfinite(x), np.isfinite(y)), (name, k)
+            fin = np.isfinite(y)
             err = np.abs(x[fin] - y[fin]) / np.maximum(np.abs(y[fin]), 1e-3)
-            close = (err <= 1e-4).all(axis=1)
-            assert close.mean() >= 0.97, (name, k, float(err.max(initial=0)))
-            worst = max(worst, float(np.median(err)) if err.size else 0.0)
-        c = same & (want["cont"] != 0)
+            assert err.max(initial=0) <= 1e-5, (name, k, float(err.max(initial=0)))
+        c = want["cont"] != 0
         x, y = got["out_dir"][c], want["od"][c]
-        fin = np.isfinite(y).all(axis=1) & np.isfinite(x).all(axis=1)
-        close = (np.abs(x[fin] - y[fin]).max(axis=1) <= 2e-4) if fin.any() else np.array([True])
-        assert close.mean() >= 0.97, (name, "out_dir")
-    assert worst <= 1e-5
+        assert np.array_equal(np.isfinite(x), np.isfinite(y)), (name, "out_dir")
+        fin = np.isfinite(y).all(axis=1)
+        err = np.abs(x[fin] - y[fin]).max(axis=1) / np.maximum(np.linalg.norm(y[fin], axis=1), 1e-3) if fin.any() else np.zeros(0)
+        assert err.max(initial=0) <= 1e-5, (name, "out_dir", float(err.max(initial=0)))
+        assert same_bits(got["out_origin"][c], want["oo"][c]), name  # the bounced ray starts at the hit position
 
 
 def test_skybox_lookup_exact(device_scenes):
@@ -159,7 +164,30 @@ def test_skybox_lookup_exact(device_scenes):
 
 
 RENDERS = ["render_teapot_96x54_8spp_d8", "render_bunny_96x54_8spp_d8", "render_dragon1_96x54_8spp_d8",
-           "render_pear_96x54_8spp_d16", "render_materials_128x72_16spp_d8", "render_materials_64x36_4spp_d1"]
+           "render_pear_96x54_8spp_d16", "render_materials_128x72_16spp_d8", "render_materials_64x36_4spp_d1",
+           "render_dragon1_240x135_64spp_d8"]
+NOISE = json.load(open(os.path.join(GOLDEN, "noise.json")))  # the reference against itself with another seed (make_golden.py noise)
+
+
+def _check_frame_vs_reference(bgr, acc, g, spp, noise_key):
+    """Image bounds, each set from a measurement (tools/dbg/measure_parity.py on the MI355X, tests/golden/noise.json on the CPU):
+    * the reference's non-finite pixels (inf/NaN surface colours of some Disney lobes times a black tail, renderer.c:69)
+      are non-finite here and no others (measured: the sets are equal on every fixture);
+    * SURVEY §7's statistical bar: RMSE of the 8-bit images <= the reference's own RMSE against itself with another
+      seed + 10 % (e.g. 10.49 -> PSNR 27.7 dB for dragon1 at 64 spp: what two CORRECT renderers with different random
+      streams reach).  With MATCHED seeds the kernels follow the reference's paths, so the bound that can fail is 100 x
+      tighter: RMSE <= 1 % of that noise floor (floor + 40 dB; measured 0.03-0.3 %, PSNR 70-86 dB);
+    * path-for-path agreement: a pixel's f32 sum agrees to 1e-4 relative unless one of its spp samples took another
+      decision where a libm ulp decides (u2 <= F, reflectance > xi, the lobe interval): at most spp x 1e-4 of the
+      pixels (measured per-sample rate 1e-5 to 5e-5 on every fixture)."""
+    assert np.array_equal(np.isfinite(g["cum"]).all(axis=2), np.isfinite(acc).all(axis=2))
+    fin = np.isfinite(g["cum"]).all(axis=2)
+    rmse = float(np.sqrt(np.mean((bgr[fin].astype(np.float64) - g["bgr"][fin].astype(np.float64)) ** 2)))
+    floor = NOISE[noise_key]["rmse_8bit"]
+    assert rmse <= 1.1 * floor and rmse <= 0.01 * floor, (rmse, floor)
+    rel = np.abs(acc[fin] - g["cum"][fin]).max(axis=1) / np.maximum(np.abs(g["cum"][fin]).max(axis=1), 1e-3)
+    assert (rel > 1e-4).mean() <= spp * 1e-4, float((rel > 1e-4).mean())
+    return rmse
 
 
 @pytest.mark.parametrize("name", RENDERS)
@@ -168,16 +196,77 @@ def test_seeded_render_vs_reference(built_scenes, device_scenes, name):
     w, h, spp, depth, lo, hi = map(int, g["meta"])
     scene = name.split("_")[1]
     bgr, acc, st = device_scenes(scene).render(built_scenes(scene).rtx_camera(), hip.make_params(w, h, spp, depth, seed=(lo, hi)))
-    # the reference itself produces non-finite pixels (inf/NaN surface colours of some Disney lobes
-    # times a black tail, renderer.c:69); they must show up in the same places, and are skipped below
-    assert (np.isfinite(g["cum"]).all(axis=2) == np.isfinite(acc).all(axis=2)).mean() >= 0.98
-    fin = np.isfinite(g["cum"]).all(axis=2) & np.isfinite(acc).all(axis=2)
-    p = psnr(bgr[fin], g["bgr"][fin])
-    assert p >= 30.0, p
-    # most pixels follow the very same paths: their sums agree to float rounding
-    rel = np.abs(acc[fin] - g["cum"][fin]).max(axis=1) / np.maximum(np.abs(g["cum"][fin]).max(axis=1), 1e-3)
-    assert (rel <= 1e-4).mean() >= 0.90, float((rel <= 1e-4).mean())
+    if depth == 1:  # primary visibility only: exact, see test_depth_one_is_primary_visibility_only
+        assert same_values(acc, g["cum"])
+    else:
+        _check_frame_vs_reference(bgr, acc, g, spp, name[7:])
     assert st["rays_at_depth"][0] == w * h * spp
+
+
+def test_config5_sample_range_split_vs_reference(built_scenes, device_scenes):
+    """BASELINE config 5 (dragon, 1024 spp, sample-range split over 8 GPUs, framebuffer reduce; renderer.c:98-110 is the
+    per-pixel sum the split must reproduce) at a size the reference finishes on the CPU: 192x108, 1024 spp, depth 8,
+    fixture rendered by the reference itself.  The 8 shares [128 r, 128 r + 128) are rendered as rtx_render_device
+    renders a rank's share — each into its own zeroed f32 buffer —, summed in rank order like the reduce, resolved with
+    the whole job's spp, and held to the reference's frame; rendered one after the other into ONE buffer they continue
+    the sequential per-pixel sum and give the single-launch frame bit for bit."""
+    import torch
+    g = golden("render_dragon1_192x108_1024spp_d8.npz")
+    w, h, spp, depth, lo, hi = map(int, g["meta"])
+    assert (w, h, spp, depth) == (192, 108, 1024, 8)
+    sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
+    cam, dev = sc.rtx_camera(), torch.device("cuda", 0)
+    world = 8
+    shares = [torch.zeros(h, w, 3, device=dev) for _ in range(world)]
+    one = torch.zeros(h, w, 3, device=dev)
+    rays = np.zeros(depth, np.int64)
+    for r in range(world):
+        p = hip.make_params(w, h, spp, depth, seed=(lo, hi), sample_range=(r * spp // world, (r + 1) * spp // world))
+        st = ds.render_device(cam, p, shares[r].data_ptr())
+        assert st["rays_at_depth"][0] == w * h * spp // world and st["camera_paths"] == w * h * spp // world
+        rays[:len(st["rays_at_depth"])] += np.array(st["rays_at_depth"])
+        ds.render_device(cam, p, one.data_ptr())
+    total = torch.zeros(h, w, 3, device=dev)
+    for r in range(world):  # the reduce: partial sums added in rank order
+        total += shares[r]
+    bgr = torch.zeros(h, w, 3, dtype=torch.uint8, device=dev)
+    ds.resolve_device(total.data_ptr(), w, h, spp, bgr.data_ptr())
+    torch.cuda.synchronize(dev)
+    # noise floor: the 64-spp figure of the same scene is an upper bound for 1024 spp (noise falls with 1/sqrt(spp))
+    rmse = _check_frame_vs_reference(bgr.cpu().numpy(), total.cpu().numpy(), g, spp, "dragon1_240x135_64spp_d8")
+    assert rmse <= 0.05  # measured 0.017 (PSNR 83.8 dB)
+    full_bgr, full, st = ds.render(cam, hip.make_params(w, h, spp, depth, seed=(lo, hi)))
+    assert same_bits(one.cpu().numpy(), full) and rays.tolist() == st["rays_at_depth"]
+    assert np.allclose(total.cpu().numpy(), full, rtol=1e-5, atol=1e-5)  # another association of the same 1024 terms
+    bgr1 = torch.zeros(h, w, 3, dtype=torch.uint8, device=dev)
+    ds.resolve_device(one.data_ptr(), w, h, spp, bgr1.data_ptr())
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(bgr1.cpu().numpy(), full_bgr)
+
+
+def test_config5_one_share_at_full_size(built_scenes, device_scenes):
+    """BASELINE config 5 at full size, ONE rank's share: 3840x2160, samples [0, 128) of 1024, depth 8 (1.06 G camera
+    paths in several slabs).  Properties that need no reference frame: one ray per camera path at depth 0, two runs
+    agree bit for bit, and the two half shares [0, 64) + [64, 128) rendered into the same buffer continue the same
+    sequential sum bit-exactly."""
+    import torch
+    sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
+    cam, dev = sc.rtx_camera(), torch.device("cuda", 0)
+    W, H, spp, depth = 3840, 2160, 1024, 8
+    bufs = [torch.zeros(H, W, 3, device=dev) for _ in range(3)]
+    sa = ds.render_device(cam, hip.make_params(W, H, spp, depth, sample_range=(0, 128)), bufs[0].data_ptr())
+    sb = ds.render_device(cam, hip.make_params(W, H, spp, depth, sample_range=(0, 128)), bufs[1].data_ptr())
+    assert sa["rays_at_depth"][0] == W * H * 128 and sa["passes"] > 1
+    assert sa["rays_at_depth"] == sb["rays_at_depth"] and all(x >= y for x, y in zip(sa["rays_at_depth"], sa["rays_at_depth"][1:]))
+    a = bufs[0].cpu().numpy()
+    assert same_bits(a, bufs[1].cpu().numpy())
+    rays = np.zeros(depth, np.int64)
+    for rng in ((0, 64), (64, 128)):
+        st = ds.render_device(cam, hip.make_params(W, H, spp, depth, sample_range=rng), bufs[2].data_ptr())
+        rays += np.array(st["rays_at_depth"])
+    assert same_bits(a, bufs[2].cpu().numpy()) and rays.tolist() == sa["rays_at_depth"]
+    fin = np.isfinite(a).all(axis=2)
+    assert fin.mean() > 0.999 and a[fin].min() >= 0.0
 
 
 def test_depth_one_is_primary_visibility_only(built_scenes, device_scenes):
