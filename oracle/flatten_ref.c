@@ -1,130 +1,3 @@
-# INTEGRATION — putting `librt_hip.so` under the reference's render loop
-
-The reference (`deggua/raytracer`) is one statically linked C program (C sources compiled as C++20 by
-clang); it has no plugin, operator or FFI layer.  The seam is its render loop (`src/rt/renderer.h:8-22`)
-and the opaque scene it hands to that loop.  This file shows what a maintainer of the reference adds
-to route `Render_Start` to the MI355X; nothing else in the reference changes.
-
-## 1. What ships
-
-| file | role |
-|---|---|
-| `raytracer_amd/lib/librt_hip.so` | the device library; C ABI in `include/rtx.h` |
-| `raytracer_amd/lib/librtx_host.so` | optional: the reference's host API re-implemented (`include/rt_host.h`) for users who do not link the reference's own objects; includes the same shim as below |
-| `include/rtx.h` | `rtx_scene_desc` (flattened pools), `rtx_camera` (bit-compatible with `Camera`, `src/world/camera.h:6-13`, 88 bytes), `rtx_render_params`, `rtx_stats`, entry points |
-
-Build: `python -m raytracer_amd.build` (or `__graft_entry__.build()`): `hipcc --offload-arch=gfx950 -O3
--ffp-contract=off` for the device library, `clang++ -O2 -ffp-contract=off` for the host library.
-
-## 2. The reference-side binding
-
-Two new files in the reference tree and one changed call.  The two files below are not a sketch: they are
-`oracle/flatten_ref.h` and `oracle/flatten_ref.c` of this repository, verbatim (`tests/test_reference_binding.py` checks
-that this section and the files stay equal), and they are **compiled against the unmodified reference** with the
-reference's own flags by `oracle/Makefile` and linked into `oracle/_ref/ref_parity`:
-
-* `Rtx_Flatten` runs over the reference's real `Scene*` and every pool it fills — kd nodes, leaf lists, triangles,
-  spheres, planes, materials, textures, skybox faces — is byte-compared with what this repository's `Scene_Flatten`
-  hands to `rtx_scene_create`, on five scenes (`test_reference_side_flattener_equals_scene_flatten`, CPU);
-* the reference's own render loop (`Render_New`, `Render_Done` polling, `Render_Delete`, its `Scene`, `Camera` and
-  `ImageRGB`) with `Render_Start` replaced by `Render_Start_HIP` renders frames on the MI355X that are byte-identical to
-  `rtx_render`'s (`test_reference_render_loop_through_render_start_hip`, GPU).
-
-`struct Scene` (`src/world/scene.c:16-22`), `struct KDTree` and `union KDNode` (`src/rt/accelerators/kdtree.c:71-133`),
-`struct Texture` (`src/gfx/texture.c:5-7`) and `Vector(T)` (`src/ctl/containers/vector.h:70-77`) are private to their `.c`
-files.  The binding re-declares them under other names; `oracle/ref_driver.c`, which `#include`s `scene.c`, `kdtree.c` and
-`texture.c` and so sees both, holds the `static_assert`s on every size and offset (a maintainer would rather move the
-four definitions into an internal header and drop the re-declarations).  This repository's own `Scene`
-(`librtx_host.so`) is NOT layout-compatible with the reference's — it keeps triangles in a compact pool (DESIGN §4.6) —
-which is why the binding is written and tested against the reference's structs, not lifted from `rt_host.cpp`.
-
-### 2.1 `src/rt/hip/flatten.h` (= `oracle/flatten_ref.h`)
-
-```c
-// oracle/flatten_ref.h — the reference-side binding of librt_hip.so, as a maintainer of deggua/raytracer would add it
-// (INTEGRATION.md §2 reproduces this file and flatten_ref.c; in the reference tree they are src/rt/hip/flatten.{h,c}).
-//
-// TEST INFRASTRUCTURE in this repository: compiled by oracle/Makefile against the UNMODIFIED reference headers, linked
-// into oracle/_ref/ref_parity, and checked by tests/test_reference_binding.py (pools byte-compared with Scene_Flatten's;
-// a frame rendered by the reference's own Render_New / Render_Done loop through Render_Start_HIP).  The product never
-// loads it.
-//
-// The flattener has to read four layouts that no reference header exports.  They are re-declared here under other names
-// ("peek" structs); oracle/ref_driver.c, the one translation unit that sees both these and the real definitions (it
-// #includes scene.c, kdtree.c and texture.c), holds the static_asserts that keep them equal (sizes and every offset).
-#pragma once
-
-#include <stddef.h>
-#include <sys/types.h>
-
-#include "rt/renderer.h" // RenderCtx, Scene (opaque), Camera, ImageRGB, Object, Material, Skybox, Texture (opaque)
-#include "rtx.h"
-
-// Vector(T), src/ctl/containers/vector.h:70-77
-typedef struct RtxPeekVector {
-    void*  at;
-    size_t length;
-    size_t capacity;
-} RtxPeekVector;
-
-// struct KDTree, src/rt/accelerators/kdtree.c:128-133
-typedef struct RtxPeekKDTree {
-    RtxPeekVector* nodes;   // Vector(KDNode): 10-byte packed nodes, kdtree.c:71-123
-    RtxPeekVector* objPtrs; // Vector(ObjectPtr): Object* into scene->kdObjects->at
-    BoundingBox    worldBox;
-    ssize_t        rootIndex;
-} RtxPeekKDTree;
-
-// struct Scene, src/world/scene.c:16-22
-typedef struct RtxPeekScene {
-    Skybox*        skybox;
-    RtxPeekVector* objects;
-    RtxPeekVector* unboundObjs; // Vector(Object): the planes, scene.c:150-156
-    RtxPeekVector* kdObjects;   // Vector(Object): everything the kd-tree holds
-    RtxPeekKDTree* kdTree;
-} RtxPeekScene;
-
-// struct Texture, src/gfx/texture.c:5-7
-typedef struct RtxPeekTexture {
-    ImageColor* image;
-} RtxPeekTexture;
-
-// union KDNode, kdtree.c:71-114: 10 bytes, little-endian.  bytes 0-3 = split (f32, inner) | len (u32, leaf);
-// bytes 4-9 = 48 bits: low 46 = leftIndex | objIndex, top 2 = type (0/1/2 = axis, 3 = leaf)
-#define RTX_PEEK_KDNODE_BYTES 10
-
-static_assert(sizeof(Object) == 112, "Object{Material*, Surface} is 112 bytes (src/world/object.h:9-18)");
-static_assert(sizeof(Material) == 64, "Material is 64 bytes (src/rt/materials.h:78-90)");
-static_assert(sizeof(Camera) == 88 && sizeof(rtx_camera) == 88, "rtx_camera is Camera (src/world/camera.h:6-13)");
-static_assert(sizeof(Vertex) == 32 && sizeof(Triangle) == 96, "Vertex{pos,norm,tex}, Triangle{vtx[3]} (src/rt/surfaces.h:29-37)");
-static_assert(sizeof(rtx_material) == 64, "rtx_material is 64 bytes");
-
-typedef struct RtxFlat {
-    rtx_scene_desc desc; // points into the arrays below
-    uint32_t *     node_w0, *node_w1, *leaf_ref, *tri_obj, *sph_obj;
-    float *        tri_pos, *tri_nrm, *tri_uv, *sph, *plane, *tex_data;
-    uint8_t *      tri_mat, *sph_mat, *plane_mat;
-    rtx_material*  materials;
-    rtx_texture_desc* textures;
-    const Material*   mat_ptr[256]; // materials[i] was made from mat_ptr[i]
-} RtxFlat;
-
-// Scene (after Scene_Prepare) -> the pools of rtx_scene_desc.  NULL + message on stderr when the scene cannot be
-// expressed (no bounded object, more than 256 materials, a Material_Skybox of another skybox).
-RtxFlat* Rtx_Flatten(const Scene* scene);
-void     Rtx_FlatDelete(RtxFlat* flat);
-
-// Render_Start (src/rt/renderer.c:265-269) with the frame rendered by librt_hip.so: same asynchronous contract —
-// returns at once, a waiter thread fills ctx->img->pix and then sets ctx->finished, Render_Done / Render_Delete unchanged.
-void Render_Start_HIP(RenderCtx* ctx, size_t samples_per_pixel, size_t max_ray_depth);
-```
-
-### 2.2 `src/rt/hip/flatten.c` (= `oracle/flatten_ref.c`): `Rtx_Flatten` and `Render_Start_HIP`
-
-Build: add the file to the reference's sources and `-ldl` to its link line (`makefile_linux:22`); `librt_hip.so` is
-found through the loader's search path or `RTX_HIP_LIB`.
-
-```c
 // oracle/flatten_ref.c — reference-side binding of librt_hip.so (see flatten_ref.h; in the reference tree this is
 // src/rt/hip/flatten.c).  Compiled with the reference's own flags against its unmodified headers: C compiled as C++20
 // by clang, common.h force-included.  It uses nothing of this repository but include/rtx.h.
@@ -434,89 +307,3 @@ void Render_Start_HIP(RenderCtx* ctx, size_t samples_per_pixel, size_t max_ray_d
     ctx->waiter_args   = arg;
     if (!Thread_Spawn(waiter, Render_Waiter_HIP, arg)) ABORT("Failed to start render waiter thread");
 }
-```
-
-### 2.3 One changed call in `src/main.c`
-
-`main.c:431` — `Render_Start(ctx, spp, depth)` → `Render_Start_HIP(ctx, spp, depth)`.  The preview loop
-(`main.c:436-478`) keeps polling `Render_Done`; with the GPU path the image appears at once when the
-frame completes instead of tile by tile.
-
-### 2.4 Optional: the SAH build on the device, inside `KDTree_New`
-
-`KDTree_New` (`src/rt/accelerators/kdtree.c:405-444`) prepares the boxes (`CreateKDBBs`, `:385-403`), the
-world box and the depth bound, then recurses (`BuildNode`, `:273-383`).  The recursion is what
-`rtx_kd_build` replaces; the tree it returns is the one the recursion would have built, word for word
-(`tests/test_kd_build_gpu.py`).  In the peek TU, next to the flattener:
-
-```c
-/* kdtree.c:437 — instead of  tree->rootIndex = BuildNode(tree, boundingBoxes, indices, worldBox, maxDepth); */
-float* flat = malloc(len * 6 * sizeof(float));          /* {min x y z, max x y z} per primitive        */
-for (size_t i = 0; i < len; i++) { /* copy boundingBoxes->at[i].min / .max */ }
-float world[6] = { wb.min.x, wb.min.y, wb.min.z, wb.max.x, wb.max.y, wb.max.z };
-rtx_kd_tree t;
-if (rtx_kd_build(0, flat, len, maxDepth, world, &t) != RTX_OK) ABORT("%s", rtx_last_error());
-/* t.node_w0/node_w1/leaf_ref are exactly the flattened pools of §2.1 (node_split_or_len, node_link,
- * leaf_ref before the kdObjects -> triangle/sphere renumbering): either hand them to the flattener
- * directly, or expand them back into KDNode (10-byte packed, :71-123) and objPtrs for the CPU path */
-rtx_kd_free(&t);
-```
-
-`librtx_host.so` does the same under the reference's names: `Scene_Prepare_External(scene, rtx_kd_build,
-rtx_kd_free, device, &ms)` / `KDTree_New_External` (`include/rt_host.h`).  1.1 M triangles: 62 ms on the
-device against 5.3 s for the host recursion.
-
-### 2.5 Optional: the preview loop keeps its image filling in
-
-`main.c:436-478` polls `Render_Done` every 200 ms and blits `ctx->img->pix` meanwhile; `:47-58` exports the
-image on SIGINT.  With `rtx_render_progressive(dev, cam, &p, spp_per_pass, ctx->img->pix, NULL, on_pass, ctx,
-&stats)` in the shim of §2.2 the image holds, after every pass, the average of the samples so far; `on_pass`
-returning nonzero (set from the SIGINT handler) ends the frame there.  A frame that runs to the end is
-byte-identical to `rtx_render`'s.  `librtx_host.so`: `Render_Set_Progressive`, `Render_Stop`,
-`Render_Samples_Done`.
-
-### 2.6 Optional: the asset path without the `Object` detour
-
-`Mesh_Import_OBJ` (`src/gfx/mesh.c:87-244`) is two `fgets`/`sscanf` loops over the file and `Mesh_AddToScene`
-(`:67-84`) builds one 112-byte `Object` per triangle, which `Scene_Prepare` copies once more (`scene.c:145-166`).
-`librtx_host.so` keeps both names and their results and changes what happens behind them: the importer's two loop
-bodies are functions of one `fgets` chunk, run over the file in memory by all cores (`Mesh_Import_OBJ_Path`,
-`Mesh_Import_OBJ_Memory`; the `FILE*` entry point stays the sequential loop), and the scene keeps triangles in one
-compact pool from which the flattener fills the SoA pools of §2.1.  A maintainer who wants the same in the
-reference moves the bodies of the two `while(!feof(fd))` loops into `static` functions of `lineBuffer`, and lets
-`Scene_Add_Object` append `obj->surface.triangle` to a `Vector(Triangle)` when `obj->surface.type ==
-SURFACE_TRIANGLE`; nothing on the render path reads `scene->objects` (48 MB / 1.1 M triangles
-import in 0.04 s, the whole scene build in 0.2 s).
-
-## 3. Calling conventions that matter
-
-* **Errors**: every `rtx_*` call returns `RTX_OK` (0) or a negative `RTX_E_*`; `rtx_last_error()` returns
-  a thread-local message.  The library never aborts and never throws.  The reference dereferences
-  NULL for a scene without bounded objects (`scene.c:109`); `rtx_scene_create` returns
-  `RTX_E_EMPTY_SCENE` instead.
-* **Ownership**: `rtx_scene_create` copies the pools; the caller keeps its arrays.  One handle per
-  (scene, device); a handle is used by one thread at a time, distinct handles are independent.
-* **Seeds**: path (pixel, sample) uses `Random_Seed(seed_lo ^ (pixel_index·spp + sample), seed_hi)`
-  where `pixel_index = y·width + x`.  The reference seeds per worker thread from `rdrand`
-  (`renderer.c:143`), so its images are not reproducible run to run; ours are, per seed.
-* **Depth**: `max_depth` counts rays per path, like `max_ray_bounces` (`renderer.c:54-59`): depth 1 is
-  primary visibility only.
-* **Partitions / multi-GPU**: `band_rows/band_rank/band_world` select interleaved row bands,
-  `sample_begin/sample_end` a sample range; each process renders its part with `rtx_render_device`
-  into a zeroed full-frame f32 buffer, sums the buffers (RCCL `reduce`), and calls
-  `rtx_resolve_device` once.  See `raytracer_amd/distributed.py` and `bench.py`.
-* **Callers that cannot allocate** (HIP graph capture, serving loops): `rtx_closest_hit_noalloc` is `rtx_trace_closest`
-  on device pointers with no `hipMalloc`/`hipFree` inside — its staging is a static 10 MB device array per GPU, so a
-  call takes at most `RTX_NOALLOC_MAX_RAYS` (2¹⁸) rays and calls on one GPU must not overlap.
-* **Python**: `raytracer_amd.hip` (ctypes over `include/rtx.h`) and `raytracer_amd.host`
-  (ctypes over `include/rt_host.h`) are the bindings the tests use; `raytracer_amd.scenes` builds the
-  benchmark scenes through the reference-named host API.
-
-## 4. Python / ctypes stub (what the tests bind)
-
-```python
-L = ctypes.CDLL("raytracer_amd/lib/librt_hip.so")
-L.rtx_scene_create.argtypes = [ctypes.POINTER(rtx_scene_desc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
-L.rtx_render.argtypes = [ctypes.c_void_p, ctypes.POINTER(rtx_camera), ctypes.POINTER(rtx_render_params),
-                         ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(rtx_stats)]
-```

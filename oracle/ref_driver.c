@@ -41,6 +41,33 @@
 #include "world/scene.c"
 #include "rt/renderer.c"
 
+// The reference-side binding of librt_hip.so (flatten_ref.c, its own translation unit, sees only the reference's
+// HEADERS and re-declares the four private layouts it has to read).  This is the one place where those re-declarations
+// and the real definitions are both visible: keep them equal.
+#include "flatten_ref.h"
+#define SAME_FIELD(Real, Peek, field) \
+    static_assert(offsetof(Real, field) == offsetof(Peek, field) && sizeof(((Real*)0)->field) == sizeof(((Peek*)0)->field), #Real "." #field)
+static_assert(sizeof(Scene) == sizeof(RtxPeekScene), "struct Scene (scene.c:16-22)");
+SAME_FIELD(Scene, RtxPeekScene, skybox);
+SAME_FIELD(Scene, RtxPeekScene, objects);
+SAME_FIELD(Scene, RtxPeekScene, unboundObjs);
+SAME_FIELD(Scene, RtxPeekScene, kdObjects);
+SAME_FIELD(Scene, RtxPeekScene, kdTree);
+static_assert(sizeof(KDTree) == sizeof(RtxPeekKDTree), "struct KDTree (kdtree.c:128-133)");
+SAME_FIELD(KDTree, RtxPeekKDTree, nodes);
+SAME_FIELD(KDTree, RtxPeekKDTree, objPtrs);
+SAME_FIELD(KDTree, RtxPeekKDTree, worldBox);
+SAME_FIELD(KDTree, RtxPeekKDTree, rootIndex);
+static_assert(sizeof(Texture) == sizeof(RtxPeekTexture), "struct Texture (texture.c:5-7)");
+SAME_FIELD(Texture, RtxPeekTexture, image);
+static_assert(sizeof(Vector(Object)) == sizeof(RtxPeekVector) && sizeof(Vector(KDNode)) == sizeof(RtxPeekVector)
+                  && sizeof(Vector(ObjectPtr)) == sizeof(RtxPeekVector), "Vector(T) (vector.h:70-77)");
+SAME_FIELD(Vector(Object), RtxPeekVector, at);
+SAME_FIELD(Vector(Object), RtxPeekVector, length);
+SAME_FIELD(Vector(KDNode), RtxPeekVector, length);
+SAME_FIELD(Vector(ObjectPtr), RtxPeekVector, at);
+static_assert(sizeof(KDNode) == RTX_PEEK_KDNODE_BYTES, "union KDNode (kdtree.c:71-114)");
+
 #define MAX_NAMED 64
 
 typedef struct {
@@ -462,6 +489,69 @@ static void mode_render(Scene* scene, size_t W, size_t H, size_t spp, size_t dep
 }
 
 // ---------------------------------------------------------------------------------------------
+// flatten: Rtx_Flatten (flatten_ref.c) over the reference's own Scene; every pool dumped for the byte comparison with
+// the product's Scene_Flatten (tests/test_reference_binding.py).
+// file: u32 magic 'RFL1', then the desc's 10 counts (n_nodes n_refs root n_tris n_spheres n_planes n_materials n_textures
+//       max_depth abi), u64 tex_texels, i32 skybox_tex[6], then the arrays in the order of rtx_scene_desc
+// ---------------------------------------------------------------------------------------------
+static void mode_flatten(Scene* scene, const char* out)
+{
+    // the packed-byte decode of flatten_ref.c against the bit-fields of the real union, node by node
+    RtxFlat* f = Rtx_Flatten(scene);
+    if (!f) ABORT("Rtx_Flatten failed");
+    const rtx_scene_desc* d = &f->desc;
+    KDTree*               t = scene->kdTree;
+    for (size_t i = 0; i < t->nodes->length; i++) {
+        KDNode* n  = &t->nodes->at[i];
+        u32     w0 = 0, w1;
+        if (n->type == KD_LEAF) w0 = (u32)n->leaf.len, w1 = (3u << 30) | (u32)n->leaf.objIndex;
+        else memcpy(&w0, &n->inode.split, 4), w1 = ((u32)n->type << 30) | (u32)n->inode.leftIndex;
+        if (d->node_w0[i] != w0 || d->node_w1[i] != w1) ABORT("node %zu decoded differently from the bit-fields", i);
+    }
+    FILE* fd = fopen(out, "wb");
+    if (!fd) ABORT("cannot write %s", out);
+    u32 hdr[11] = {0x314c4652, d->n_nodes, d->n_refs, d->root_index, d->n_tris, d->n_spheres, d->n_planes, d->n_materials, d->n_textures, d->max_depth, d->abi_version};
+    put(fd, hdr, sizeof hdr);
+    put(fd, &d->tex_texels, 8);
+    put(fd, d->skybox_tex, sizeof d->skybox_tex);
+    const size_t T = d->n_tris, S = d->n_spheres, P = d->n_planes;
+    put(fd, d->node_w0, 4ull * d->n_nodes), put(fd, d->node_w1, 4ull * d->n_nodes), put(fd, d->leaf_ref, 4ull * d->n_refs);
+    put(fd, d->tri_pos, 36 * T), put(fd, d->tri_nrm, 36 * T), put(fd, d->tri_uv, 24 * T), put(fd, d->tri_mat, T), put(fd, d->tri_obj, 4 * T);
+    put(fd, d->sph, 16 * S), put(fd, d->sph_mat, S), put(fd, d->sph_obj, 4 * S);
+    put(fd, d->plane, 24 * P), put(fd, d->plane_mat, P);
+    put(fd, d->materials, sizeof(rtx_material) * d->n_materials), put(fd, d->textures, sizeof(rtx_texture_desc) * d->n_textures);
+    put(fd, d->tex_data, 12ull * d->tex_texels);
+    fclose(fd);
+    printf("{\"nodes\": %u, \"refs\": %u, \"tris\": %u, \"spheres\": %u, \"planes\": %u, \"materials\": %u, \"textures\": %u, \"texels\": %llu}\n",
+           d->n_nodes, d->n_refs, d->n_tris, d->n_spheres, d->n_planes, d->n_materials, d->n_textures, (unsigned long long)d->tex_texels);
+    Rtx_FlatDelete(f);
+}
+
+// render_hip: the reference's own render loop — Render_New, Render_Done polling, Render_Delete, its Scene, Camera and
+// ImageRGB — with ONE call changed: Render_Start -> Render_Start_HIP (flatten_ref.c).  Needs librt_hip.so (RTX_HIP_LIB)
+// and an MI355X; RTX_SEED_LO / RTX_SEED_HI pin the frame.  file: W*H x u8[3] = ImageRGB.pix
+static void mode_render_hip(Scene* scene, size_t W, size_t H, size_t spp, size_t depth, const char* out)
+{
+    ImageRGB img;
+    ImageRGB_Load_Empty(&img, W, H);
+    RenderCtx* ctx = Render_New(scene, &img, g_cam);
+    f64        t0  = now_s();
+    Render_Start_HIP(ctx, spp, depth);
+    while (!Render_Done(ctx)) { // main.c:464,477 polls every 200 ms
+        struct timespec ts = {0, 2000000};
+        nanosleep(&ts, NULL);
+    }
+    f64 t1 = now_s();
+    Thread_Join(ctx->waiter_thread);
+    FILE* fd = fopen(out, "wb");
+    if (!fd) ABORT("cannot write %s", out);
+    put(fd, img.pix, W * H * 3);
+    fclose(fd);
+    printf("{\"width\": %zu, \"height\": %zu, \"spp\": %zu, \"depth\": %zu, \"seconds\": %.6f}\n", W, H, spp, depth, t1 - t0);
+    Render_Delete(ctx);
+}
+
+// ---------------------------------------------------------------------------------------------
 // bounce: single Material_Bounce calls.
 // in : records of {u32 material_index, f32 ray_dir[3], pos[3], normal[3], uv[2], u32 front, u64 seed_lo, seed_hi}
 // out: records of {u32 cont, f32 surface[3], emitted[3], out_origin[3], out_dir[3], u32 rng_after[4](next 4 draws' bits)}
@@ -589,6 +679,8 @@ int main(int argc, char** argv)
                 "       ... render W H spp depth seed_lo seed_hi threads out.bin\n"
                 "       ... bounce in.bin out.bin\n"
                 "       ... sky in.bin out.bin\n"
+                "       ... flatten out.bin\n"
+                "       ... render_hip W H spp depth out.bin\n"
                 "       ... bench W H spp depth [out.bmp]\n",
                 argv[0], argv[0]);
         return 2;
@@ -619,6 +711,10 @@ int main(int argc, char** argv)
         mode_bounce(a[0], a[1]);
     } else if (!strcmp(mode, "sky") && n == 2) {
         mode_sky(scene, a[0], a[1]);
+    } else if (!strcmp(mode, "flatten") && n == 1) {
+        mode_flatten(scene, a[0]);
+    } else if (!strcmp(mode, "render_hip") && n == 5) {
+        mode_render_hip(scene, strtoull(a[0], 0, 0), strtoull(a[1], 0, 0), strtoull(a[2], 0, 0), strtoull(a[3], 0, 0), a[4]);
     } else if (!strcmp(mode, "bench") && (n == 4 || n == 5)) {
         mode_bench(scene, strtoull(a[0], 0, 0), strtoull(a[1], 0, 0), strtoull(a[2], 0, 0), strtoull(a[3], 0, 0),
                    n == 5 ? a[4] : "");
