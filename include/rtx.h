@@ -215,7 +215,10 @@ int rtx_trace_closest(rtx_scene* scene, size_t n, const float* origin_xyz, const
 
 /* Same query on device-resident SoA rays (ox,oy,oz,dx,dy,dz each n floats at rays+c*n), already
  * normalised by a previous Ray_Make; writes prim ref/t/u/v (4 x n dwords, SoA) to `hits`.
- * Asynchronous on `stream` (a hipStream_t); this is the entry bench.py times. */
+ * Asynchronous on `stream` (a hipStream_t).
+ * SERIALISE the calls on one rtx_scene: every call that takes a scene handle (this one, rtx_render*, rtx_trace_closest)
+ * uses that scene's work counters, workspace and events; two such calls in flight at once — from two threads or on two
+ * streams — race.  Distinct rtx_scene handles are independent. */
 int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, uint32_t* d_hits,
                              void* stream, uint32_t flags, uint64_t* d_visit_counters /* 4 x u64: inner, leaf, prim, culled */);
 

@@ -233,6 +233,30 @@ static int validate_desc(const rtx_scene_desc* d)
             if (idx >= d->n_nodes || i + 1 >= d->n_nodes) return fail(RTX_E_INVALID, "inner node %u has a child out of range", i);
         }
     }
+    // ... and the SHAPE the walks rely on: what hangs below the root must be a tree — a node reached twice is a cycle (the
+    // device walk and build_cull_data's walk would never end) or a shared subtree — no deeper than the traversal stack:
+    // a walk keeps at most one pending far child per inner node on its path, and the per-lane stack has
+    // min(max_depth, RTX_STACK) entries.  desc.max_depth is a promise; the depth is measured here.
+    {
+        std::vector<uint8_t>  seen(d->n_nodes, 0);
+        std::vector<uint64_t> st; // node | level << 32
+        st.push_back(d->root_index);
+        uint32_t deepest = 0;
+        while (!st.empty()) {
+            const uint32_t n = (uint32_t)st.back(), level = (uint32_t)(st.back() >> 32);
+            st.pop_back();
+            if (seen[n]) return fail(RTX_E_INVALID, "kd node %u is reached twice from the root (a cycle or a shared subtree): not a tree", n);
+            seen[n] = 1;
+            deepest = std::max(deepest, level);
+            if (level + 1 > std::min<uint32_t>(d->max_depth, RTX_STACK))
+                return fail(RTX_E_LIMIT, "kd-tree is deeper than %u levels (desc.max_depth %u, traversal stack %d) at node %u",
+                            std::min<uint32_t>(d->max_depth, RTX_STACK), d->max_depth, RTX_STACK, n);
+            if ((d->node_w1[n] >> 30) != 3u) {
+                st.push_back((uint64_t)(level + 1) << 32 | (n + 1));
+                st.push_back((uint64_t)(level + 1) << 32 | (d->node_w1[n] & 0x3FFFFFFFu));
+            }
+        }
+    }
     for (uint32_t i = 0; i < d->n_refs; i++) {
         uint32_t r = d->leaf_ref[i];
         if ((r & RTX_REF_SPHERE) ? ((r & 0x7FFFFFFFu) >= d->n_spheres) : (r >= d->n_tris)) return fail(RTX_E_INVALID, "leaf reference %u out of range", i);
@@ -2271,9 +2295,13 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
     HIPCHECK(brays.alloc(m * 24));
     HIPCHECK(bhits.alloc(m * 16));
     HIPCHECK(hipMemset(sc->d_counters, 0, 16 * sizeof(uint64_t)));
-    hipEvent_t e0, e1;
-    HIPCHECK(hipEventCreate(&e0));
-    HIPCHECK(hipEventCreate(&e1));
+    struct EventPair { // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evp;
+    HIPCHECK(hipEventCreate(&evp.a));
+    HIPCHECK(hipEventCreate(&evp.b));
+    const hipEvent_t e0 = evp.a, e1 = evp.b;
     double ms_total = 0.0;
     for (size_t off = 0; off < n; off += CH) {
         size_t k = std::min(CH, n - off);
@@ -2299,8 +2327,6 @@ extern "C" int rtx_trace_closest(rtx_scene* sc, size_t n, const float* origin_xy
         if (uv) HIPCHECK(hipMemcpy(uv + 2 * off, buv.p, k * 8, hipMemcpyDeviceToHost));
         if (front_face) HIPCHECK(hipMemcpy(front_face + off, bf.p, k, hipMemcpyDeviceToHost));
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (stats) {
         stats->rays_total       = n;
         stats->rays_at_depth[0] = n;
@@ -2427,7 +2453,28 @@ static int get_event(rtx_scene* sc, int i, hipEvent_t* ev)
     return RTX_OK;
 }
 
+static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, float* d_accum, void* stream, rtx_stats* stats);
+
 extern "C" int rtx_render_device(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, float* d_accum, void* stream, rtx_stats* stats)
+{
+    const int rc = render_device_impl(sc, cam, p, d_accum, stream, stats);
+    if (rc != RTX_OK && sc) {
+        // A failure in the middle of a frame leaves kernels and the copies of the survivor counts in flight on the caller's
+        // stream and on the lanes' own streams; the next call may regrow (free) the workspace they use or reuse their events.
+        // Drain them before reporting — errors of the draining itself are ignored, the message is the first failure's.
+        char first[sizeof g_err];
+        memcpy(first, g_err, sizeof first);
+        (void)hipSetDevice(sc->device);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        for (int l = 0; l < RTX_MAX_LANES - 1; l++)
+            if (sc->aux_stream[l]) (void)hipStreamSynchronize(sc->aux_stream[l]);
+        (void)hipGetLastError();
+        memcpy(g_err, first, sizeof first);
+    }
+    return rc;
+}
+
+static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_render_params* p, float* d_accum, void* stream, rtx_stats* stats)
 {
     if (!sc || !cam || !d_accum) return fail(RTX_E_INVALID, "null argument");
     FrameGeom g;

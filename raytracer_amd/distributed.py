@@ -9,10 +9,12 @@ Every (pixel, sample) path is independent and carries its own RNG stream keyed b
   sample split  rank r traces samples [r*spp/world, (r+1)*spp/world) of every pixel.
 
 The one exchange step is a sum-reduce of the f32 accumulation buffer to rank 0
-(torch.distributed.reduce — RCCL over xGMI with the nccl backend, gloo in the CPU tests): with a
-tile split the supports are disjoint so the sum is a gather; with a sample split it is the sum the
-reference's RenderPixel would have formed sequentially (src/rt/renderer.c:98-107).  Rank 0 then
-applies avg = sum * (1/spp) and RGB_FromColor.
+(torch.distributed.reduce — RCCL over xGMI with the nccl backend, gloo in the CPU tests).  With a
+tile split the supports are disjoint, so the sum is a gather and the frame is BIT-EXACT the single-GPU
+frame.  With a sample split every rank forms the sequential sum of ITS samples and the reduce adds those
+partial sums: the same terms as RenderPixel's sequential sum (src/rt/renderer.c:98-107) in another f32
+association, equal to rounding (rtol 1e-5 in the tests), not bit for bit.  Rank 0 then applies
+avg = sum * (1/spp) and RGB_FromColor.
 """
 from dataclasses import dataclass
 

@@ -157,3 +157,65 @@ def test_boxes_do_not_depend_on_the_node_numbering(built_scenes):
     assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and np.array_equal(q2[new_of_old], q1)
     rays = golden("trace_teapot.npz")["rays"][:4000]
     _same(O.trace(C.pointer(d2), rays[:, :3], rays[:, 3:], cull=(q2, i2)), O.trace(sc.desc, rays[:, :3], rays[:, 3:]))
+
+
+def _desc_with_nodes(d, w0, w1, root=None, max_depth=None):
+    import ctypes as C
+    d2 = type(d)()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+    d2.node_w0 = w0.ctypes.data_as(C.POINTER(C.c_uint32))
+    d2.node_w1 = w1.ctypes.data_as(C.POINTER(C.c_uint32))
+    d2.n_nodes = len(w0)
+    if root is not None:
+        d2.root_index = root
+    if max_depth is not None:
+        d2.max_depth = max_depth
+    return d2
+
+
+def test_malformed_trees_are_refused_on_the_host(built_scenes):
+    """validate_desc (every entry point that takes an rtx_scene_desc goes through it) checks the kd-tree's SHAPE, not
+    only its indices: a child that points back at an ancestor (the device walk would spin, the host walk would never
+    end), a subtree with two parents, and a tree deeper than the traversal stack or than desc.max_depth promises are
+    refused with RTX_E_INVALID / RTX_E_LIMIT before anything reaches the GPU."""
+    import ctypes as C
+    sc = built_scenes("teapot")
+    d = sc.desc.contents
+    n = d.n_nodes
+    w0 = np.ctypeslib.as_array(d.node_w0, (n,)).copy()
+    w1 = np.ctypeslib.as_array(d.node_w1, (n,)).copy()
+    hip.cull_data(sc.desc)  # the tree as built is fine
+    inner = np.nonzero((w1 >> 30) != 3)[0]
+    # a cycle: some inner node's left child becomes the root
+    deep = int(inner[len(inner) // 2])
+    c1 = w1.copy()
+    c1[deep] = (c1[deep] & 0xC0000000) | int(d.root_index)
+    with pytest.raises(hip.RtxError) as e:
+        hip.cull_data(C.pointer(_desc_with_nodes(d, w0, c1)))
+    assert e.value.code == -1 and "reached twice" in str(e.value)
+    # a shared subtree: the root's left child is also its right child's left child (if that is an inner node)
+    r = int(d.root_index)
+    if (w1[r + 1] >> 30) != 3:
+        c2 = w1.copy()
+        c2[r + 1] = (c2[r + 1] & 0xC0000000) | (w1[r] & 0x3FFFFFFF)
+        with pytest.raises(hip.RtxError) as e:
+            hip.cull_data(C.pointer(_desc_with_nodes(d, w0, c2)))
+        assert e.value.code == -1
+    # deeper than promised: the real tree with a smaller max_depth
+    with pytest.raises(hip.RtxError) as e:
+        hip.cull_data(C.pointer(_desc_with_nodes(d, w0, w1, max_depth=5)))
+    assert e.value.code == -5
+    # deeper than the traversal stack (RTX_STACK = 64) although max_depth says 64: a right spine of `k` inner nodes
+    # 0..k-1 (right child = node + 1), node k = the leaf that ends it, nodes k+1..2k = each inner node's own empty left leaf
+    def spine(k):
+        t0, t1 = np.zeros(2 * k + 1, np.uint32), np.zeros(2 * k + 1, np.uint32)
+        t1[:k] = (0 << 30) | (k + 1 + np.arange(k, dtype=np.uint32))
+        t1[k:] = (3 << 30) | 0  # len 0
+        return _desc_with_nodes(d, t0, t1, root=0, max_depth=64), t0, t1
+
+    d80, *keep = spine(80)
+    with pytest.raises(hip.RtxError) as e:
+        hip.cull_data(C.pointer(d80))
+    assert e.value.code == -5 and "deeper" in str(e.value)
+    d40, *keep2 = spine(40)  # the same shape within the limit is accepted
+    hip.cull_data(C.pointer(d40))
