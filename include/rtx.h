@@ -201,8 +201,8 @@ int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
 /* Parity seam for the culled walk (host only, needs no device): the conservative, quantised subtree
  * boxes rtx_scene_create uploads — qbox6: n_nodes x {min x y z, max x y z} as 16-bit steps of the grid
  * lo + q * scale (min.x = 0xFFFF with max.x = 0 meaning "never cull") — and info14 = {centre xyz, origin
- * radius^2, tMax stretch, lo xyz, scale xyz, magic xyz}, where the device decodes a coordinate as
- * fma(2^23 + q, scale, magic), so that a CPU checker can replay the very same culling decisions.  No
+ * radius^2, tMax stretch, lo xyz, scale xyz, 0 0 0}, where the device evaluates a plane's ray parameter as
+ * fma(float(q), scale, -(o - lo)) * (1/d), so that a CPU checker can replay the very same culling decisions.  No
  * counterpart in the reference (its KDTree.worldBox, kdtree.c:435, is never used by the traversal). */
 int rtx_cull_data_build(const rtx_scene_desc* desc, uint16_t* qbox6, float* info14);
 

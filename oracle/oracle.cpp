@@ -269,10 +269,11 @@ struct Cull {
     const uint16_t* qbox; // 6 per node: min x y z, max x y z on the 16-bit grid; min.x = 0xFFFF, max.x = 0: never cull
     vec3            c;
     f32             ro2, kt;
-    vec3            lo, scale, magic; // coordinate = fma(2^23 + q, scale, magic)
+    vec3            lo, scale; // grid x(q) = lo + q * scale
     // per ray
     bool ok;
     vec3 o, inv; // origin, and 1/dir with infinities replaced by +-3e38
+    vec3 nol;    // -(o - lo), one rounding per axis
 };
 
 struct Scene {
@@ -289,29 +290,22 @@ static void cull_begin_ray(Cull* c, const Ray* ray)
     c->inv = vec(fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x, fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y,
                  fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z);
     c->o   = o;
+    c->nol = vec(-(o.x - c->lo.x), -(o.y - c->lo.y), -(o.z - c->lo.z));
     const f32 rx = o.x - c->c.x, ry = o.y - c->c.y, rz = o.z - c->c.z;
     const f32 r2 = rx * rx + ry * ry + rz * rz;
     const f32 d2 = ray->dir.x * ray->dir.x + ray->dir.y * ray->dir.y + ray->dir.z * ray->dir.z;
     c->ok        = r2 <= c->ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
 }
 
-static inline f32 box_coord(u32 q, f32 scale, f32 magic)
-{
-    const u32 bits = 0x4B000000u | q; // the float 2^23 + q, exactly
-    f32       f;
-    memcpy(&f, &bits, 4);
-    return fmaf(f, scale, magic);
-}
+// a box plane's ray parameter, as the device computes it: fma(float(q), scale, -(o - lo)) * inv
+static inline f32 plane_t(u32 q, f32 scale, f32 nol, f32 inv) { return fmaf((f32)q, scale, nol) * inv; }
 
 static bool cull_node(const Cull* c, u32 node, f32 tMax)
 {
     const uint16_t* q = c->qbox + 6ull * node;
-    const f32 bx0 = box_coord(q[0], c->scale.x, c->magic.x), bx1 = box_coord(q[3], c->scale.x, c->magic.x);
-    const f32 by0 = box_coord(q[1], c->scale.y, c->magic.y), by1 = box_coord(q[4], c->scale.y, c->magic.y);
-    const f32 bz0 = box_coord(q[2], c->scale.z, c->magic.z), bz1 = box_coord(q[5], c->scale.z, c->magic.z);
-    const f32 t1x = (bx0 - c->o.x) * c->inv.x, t2x = (bx1 - c->o.x) * c->inv.x;
-    const f32 t1y = (by0 - c->o.y) * c->inv.y, t2y = (by1 - c->o.y) * c->inv.y;
-    const f32 t1z = (bz0 - c->o.z) * c->inv.z, t2z = (bz1 - c->o.z) * c->inv.z;
+    const f32 t1x = plane_t(q[0], c->scale.x, c->nol.x, c->inv.x), t2x = plane_t(q[3], c->scale.x, c->nol.x, c->inv.x);
+    const f32 t1y = plane_t(q[1], c->scale.y, c->nol.y, c->inv.y), t2y = plane_t(q[4], c->scale.y, c->nol.y, c->inv.y);
+    const f32 t1z = plane_t(q[2], c->scale.z, c->nol.z, c->inv.z), t2z = plane_t(q[5], c->scale.z, c->nol.z, c->inv.z);
     const f32 tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
     const f32 tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
     return c->ok && !(q[0] == 0xFFFFu && q[3] == 0u) && tn > tf;
@@ -1178,7 +1172,6 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* q
         cull.kt     = info14[4];
         cull.lo     = vec(info14[5], info14[6], info14[7]);
         cull.scale  = vec(info14[8], info14[9], info14[10]);
-        cull.magic  = vec(info14[11], info14[12], info14[13]);
         sc.cull     = &cull;
     }
     for (size_t i = 0; i < n; i++) {

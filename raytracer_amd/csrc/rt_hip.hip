@@ -310,7 +310,7 @@ static int validate_desc(const rtx_scene_desc* d)
 struct CullData {
     std::vector<uint16_t> q16; // 6 per node: min x y z, max x y z on the grid; min.x = 0xFFFF, max.x = 0: never cull
     float                 c[3], ro2, kt;
-    float                 lo[3], scale[3], magic[3]; // grid: x = lo + q * scale = fma(2^23 + q, scale, magic)
+    float                 lo[3], scale[3]; // grid: x = lo + q * scale, both binary32 values taken exactly
     bool                  useful;                    // median triangle pad below its own size
 };
 
@@ -428,26 +428,26 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
             for (int a = 0; a < 3; a++) blo[3 * n + a] = std::min(blo[3 * l + a], blo[3 * r + a]), bhi[3 * n + a] = std::max(bhi[3 * l + a], bhi[3 * r + a]);
         }
     }
-    // Quantise to 16 bits per axis on a grid over all finite boxes (+3 steps of margin on every side).  The kernel
-    // decodes a coordinate with ONE integer instruction and the fma it needs anyway: the 16-bit value is OR-ed into
-    // the mantissa of 2^23 (= 0x4B000000), which is the float 2^23 + q exactly, and x = fma(2^23 + q, scale, magic)
-    // with magic = fl(lo - 2^23 * scale).  The grid origin used for quantising is therefore lo_eff = magic + 2^23 * scale
-    // (exact in double), so that decoded planes are lo_eff + q * scale up to the one rounding of the fma (<= 1 ulp of
-    // the coordinate).  Box minima round down and maxima round up, plus one further step outward.  A node with an
-    // unbounded box is marked "never cull".
+    // Quantise to 16 bits per axis on a grid over all finite boxes (+3 steps of margin on every side).  The grid is
+    // x(q) = lo + q * scale with lo and scale the binary32 values the kernel holds, taken exactly (the quantisation below
+    // runs in double against those very values).  The kernel evaluates a plane's ray parameter as
+    // fma(float(q), scale, -fl(o - lo)) * inv: against the exact (x(q) - o) * inv that is off by eps |o - lo| (the rounded
+    // origin offset) + eps |x(q) - o| (the fma) + eps |t| (the product), a displacement of the plane by at most
+    // eps (|o - lo| + 2 |x - o|) <= 5.2 eps D — inside the 32 eps D every primitive's pad carries for the box test.
+    // Box minima round down and maxima round up, plus one further step outward.  A node with an unbounded box is
+    // marked "never cull".
     double glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t k = 0; k < 3 * (T + Sn); k++)
         if (std::isfinite(plo[k]) && std::isfinite(phi[k])) glo[k % 3] = std::min(glo[k % 3], plo[k]), ghi[k % 3] = std::max(ghi[k % 3], phi[k]);
-    const double LEVELS = 65535.0, TWO23 = 8388608.0;
+    const double LEVELS = 65535.0;
     double       scale[3];
     for (int a = 0; a < 3; a++) {
         if (!(glo[a] <= ghi[a])) glo[a] = 0.0, ghi[a] = 1.0; // no finite box at all
         const double ext = std::max(ghi[a] - glo[a], 1e-6);
         out.scale[a]     = (float)(ext / (LEVELS - 8.0));
         scale[a]         = (double)out.scale[a];
-        out.magic[a]     = (float)(glo[a] - 4.0 * scale[a] - TWO23 * scale[a]);
-        glo[a]           = (double)out.magic[a] + TWO23 * scale[a]; // the origin the kernel's decode implies
-        out.lo[a]        = (float)glo[a];
+        out.lo[a]        = (float)(glo[a] - 4.0 * scale[a]);
+        glo[a]           = (double)out.lo[a]; // the origin the kernel decodes against
     }
     out.q16.assign(6 * N, 0);
     parallel_ranges(N, [&](size_t n_lo, size_t n_hi) {
@@ -484,7 +484,7 @@ extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint16_t* qbox6, flo
     CullData cd;
     build_cull_data(d, cd);
     memcpy(qbox6, cd.q16.data(), cd.q16.size() * sizeof(uint16_t));
-    for (int a = 0; a < 3; a++) info14[a] = cd.c[a], info14[5 + a] = cd.lo[a], info14[8 + a] = cd.scale[a], info14[11 + a] = cd.magic[a];
+    for (int a = 0; a < 3; a++) info14[a] = cd.c[a], info14[5 + a] = cd.lo[a], info14[8 + a] = cd.scale[a], info14[11 + a] = 0.0f;
     info14[3] = cd.ro2;
     info14[4] = cd.kt;
     return RTX_OK;
@@ -548,7 +548,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
             UP(upload(sc, n32.data(), n32.size(), &S.nodes32));
             pack_box(&cd.q16[6 * (size_t)d->root_index], S.root_q);
         }
-        for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a], S.cull_magic[a] = cd.magic[a];
+        for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a];
         S.cull_ro2 = cd.ro2;
         S.cull_kt  = cd.kt;
         for (int a = 0; a < 3; a++) S.bin_inv[a] = (float)(1 << BIN_CELL_BITS) / (cd.scale[a] * 65535.0f); // cells over the box grid
@@ -1455,8 +1455,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     // reach is neither fetched nor pushed
                     bool miss[2];
                     box_missed2(S, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, o, inv, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
-                    missNear = cullOK && (goRight ? miss[1] : miss[0]);
-                    missFar  = cullOK && (goRight ? miss[0] : miss[1]);
+                    // (xor / and of lane masks are scalar instructions; `goRight ? miss[1] : miss[0]` made the compiler turn
+                    // both flags into 0/1 registers and select those: 8 vector instructions per step)
+                    const bool differ = miss[0] != miss[1], swap = goRight && differ;
+                    missNear = cullOK && (miss[0] != swap);
+                    missFar  = cullOK && (miss[1] != swap);
                     if (COUNT) vis.culled += (missNear ? 1u : 0u) + (farPending && missFar ? 1u : 0u);
                 }
                 const bool pushFar = farPending && !missFar;

@@ -42,13 +42,13 @@ struct SceneDev {
     // culled kernel (k_trace_flat<.., CULL>): 32 B per node, the node and the conservative boxes of BOTH children,
     // so that a child the ray cannot reach is never fetched:
     //   [0] = {w0, w1, L.x, L.y}   [1] = {L.z, R.x, R.y, R.z}      L / R = left (index in w1) / right (node + 1) child
-    // a box is three words, one per axis, max << 16 | min, on the 16-bit grid  coordinate = cull_lo + q * cull_scale
-    // = fma(2^23 + q, cull_scale, cull_magic);  min.x = 0xFFFF with max.x = 0: never cull.  root_q = the root's box.
+    // a box is three words, one per axis, max << 16 | min, on the 16-bit grid  coordinate = cull_lo + q * cull_scale;
+    // min.x = 0xFFFF with max.x = 0: never cull.  root_q = the root's box.
     const uint4*    nodes32;
     uint32_t        root_q[3];
     float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
-    float           cull_lo[3], cull_scale[3], cull_magic[3];
+    float           cull_lo[3], cull_scale[3];
     float           bin_inv[3]; // ray binning: 32 cells per axis over the box grid, cell = (o - cull_lo) * bin_inv
     const uint32_t* leaf_ref; // pool bit | pool index
     // hot triangle pool, TRI_BYTES bytes per triangle:
@@ -315,20 +315,19 @@ DEV void Triangle_HitAt2(f3x2 v0, f3x2 e1, f3x2 e2, f3 o, f3 d, float tMin, floa
 
 // Conservative box tests of the culled walk (not part of the reference).  Does the segment
 // {o + t d, 0 <= t <= kt * tMax} miss the box (wx, wy, wz)?  Each word holds one axis, max << 16 | min, on the
-// 16-bit grid; a coordinate is decoded by OR-ing it into the mantissa of 2^23 (the float 2^23 + q, exactly) and one
-// fma with (scale, magic).  `inv` is 1/d with infinities replaced by +-3e38.  The two-box form tests both children
-// of a node at once with packed math: component 0 = left child, 1 = right child (oracle/oracle.cpp replays the same
-// operations).
-#define BOX_LO(w) __uint_as_float(0x4B000000u | ((w) & 0xFFFFu))
-#define BOX_HI(w) __uint_as_float(0x4B000000u | ((w) >> 16))
+// 16-bit grid  x(q) = cull_lo + q * cull_scale.  A plane's ray parameter is  fma(float(q), scale, -(o - lo)) * inv:
+// one conversion (the 16-bit half is picked by the conversion's operand selector, no shift or mask), one fused
+// multiply-add that decodes the plane AND subtracts the origin, one multiplication.  `inv` is 1/d with infinities
+// replaced by +-3e38.  The two-box form tests both children of a node at once with packed math: component 0 = left
+// child, 1 = right child (oracle/oracle.cpp replays the same operations).
+#define BOX_LO(w) ((float)((w) & 0xFFFFu))
+#define BOX_HI(w) ((float)((w) >> 16))
 DEV bool box_missed(const SceneDev& S, uint32_t wx, uint32_t wy, uint32_t wz, f3 o, f3 inv, float tMax)
 {
-    const float bx0 = fmaf(BOX_LO(wx), S.cull_scale[0], S.cull_magic[0]), bx1 = fmaf(BOX_HI(wx), S.cull_scale[0], S.cull_magic[0]);
-    const float by0 = fmaf(BOX_LO(wy), S.cull_scale[1], S.cull_magic[1]), by1 = fmaf(BOX_HI(wy), S.cull_scale[1], S.cull_magic[1]);
-    const float bz0 = fmaf(BOX_LO(wz), S.cull_scale[2], S.cull_magic[2]), bz1 = fmaf(BOX_HI(wz), S.cull_scale[2], S.cull_magic[2]);
-    const float t1x = (bx0 - o.x) * inv.x, t2x = (bx1 - o.x) * inv.x;
-    const float t1y = (by0 - o.y) * inv.y, t2y = (by1 - o.y) * inv.y;
-    const float t1z = (bz0 - o.z) * inv.z, t2z = (bz1 - o.z) * inv.z;
+    const float nx = -(o.x - S.cull_lo[0]), ny = -(o.y - S.cull_lo[1]), nz = -(o.z - S.cull_lo[2]);
+    const float t1x = fmaf(BOX_LO(wx), S.cull_scale[0], nx) * inv.x, t2x = fmaf(BOX_HI(wx), S.cull_scale[0], nx) * inv.x;
+    const float t1y = fmaf(BOX_LO(wy), S.cull_scale[1], ny) * inv.y, t2y = fmaf(BOX_HI(wy), S.cull_scale[1], ny) * inv.y;
+    const float t1z = fmaf(BOX_LO(wz), S.cull_scale[2], nz) * inv.z, t2z = fmaf(BOX_HI(wz), S.cull_scale[2], nz) * inv.z;
     const float tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
     const float tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * S.cull_kt));
     return wx != 0x0000FFFFu && tn > tf;
@@ -338,15 +337,12 @@ DEV void box_missed2(const SceneDev& S, uint32_t lx, uint32_t ly, uint32_t lz, u
                      bool miss[2])
 {
     const f2v sx = f2v{S.cull_scale[0], S.cull_scale[0]}, sy = f2v{S.cull_scale[1], S.cull_scale[1]}, sz = f2v{S.cull_scale[2], S.cull_scale[2]};
-    const f2v mx = f2v{S.cull_magic[0], S.cull_magic[0]}, my = f2v{S.cull_magic[1], S.cull_magic[1]}, mz = f2v{S.cull_magic[2], S.cull_magic[2]};
-    const f2v ox = f2v{o.x, o.x}, oy = f2v{o.y, o.y}, oz = f2v{o.z, o.z};
+    const float nx1 = -(o.x - S.cull_lo[0]), ny1 = -(o.y - S.cull_lo[1]), nz1 = -(o.z - S.cull_lo[2]);
+    const f2v nx = f2v{nx1, nx1}, ny = f2v{ny1, ny1}, nz = f2v{nz1, nz1};
     const f2v ix = f2v{inv.x, inv.x}, iy = f2v{inv.y, inv.y}, iz = f2v{inv.z, inv.z};
-    const f2v bx0 = __builtin_elementwise_fma(f2v{BOX_LO(lx), BOX_LO(rx)}, sx, mx), bx1 = __builtin_elementwise_fma(f2v{BOX_HI(lx), BOX_HI(rx)}, sx, mx);
-    const f2v by0 = __builtin_elementwise_fma(f2v{BOX_LO(ly), BOX_LO(ry)}, sy, my), by1 = __builtin_elementwise_fma(f2v{BOX_HI(ly), BOX_HI(ry)}, sy, my);
-    const f2v bz0 = __builtin_elementwise_fma(f2v{BOX_LO(lz), BOX_LO(rz)}, sz, mz), bz1 = __builtin_elementwise_fma(f2v{BOX_HI(lz), BOX_HI(rz)}, sz, mz);
-    const f2v t1x = (bx0 - ox) * ix, t2x = (bx1 - ox) * ix;
-    const f2v t1y = (by0 - oy) * iy, t2y = (by1 - oy) * iy;
-    const f2v t1z = (bz0 - oz) * iz, t2z = (bz1 - oz) * iz;
+    const f2v t1x = __builtin_elementwise_fma(f2v{BOX_LO(lx), BOX_LO(rx)}, sx, nx) * ix, t2x = __builtin_elementwise_fma(f2v{BOX_HI(lx), BOX_HI(rx)}, sx, nx) * ix;
+    const f2v t1y = __builtin_elementwise_fma(f2v{BOX_LO(ly), BOX_LO(ry)}, sy, ny) * iy, t2y = __builtin_elementwise_fma(f2v{BOX_HI(ly), BOX_HI(ry)}, sy, ny) * iy;
+    const f2v t1z = __builtin_elementwise_fma(f2v{BOX_LO(lz), BOX_LO(rz)}, sz, nz) * iz, t2z = __builtin_elementwise_fma(f2v{BOX_HI(lz), BOX_HI(rz)}, sz, nz) * iz;
     const f2v tk  = tMax * f2v{S.cull_kt, S.cull_kt};
 #pragma unroll
     for (int k = 0; k < 2; k++) {

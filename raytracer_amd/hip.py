@@ -158,8 +158,7 @@ def cull_never(qbox):
 
 def cull_boxes_world(qbox, info):
     """Decode (qbox, info) to world-space boxes [n, 6] (min xyz, max xyz); 'never cull' nodes come out infinite."""
-    scale, magic = info[8:11].astype(np.float64), info[11:14].astype(np.float64)
-    lo = magic + 8388608.0 * scale  # what fma(2^23 + q, scale, magic) decodes to at q = 0
+    lo, scale = info[5:8].astype(np.float64), info[8:11].astype(np.float64)  # the grid x(q) = lo + q * scale
     b = np.concatenate([lo + qbox[:, :3].astype(np.float64) * scale, lo + qbox[:, 3:].astype(np.float64) * scale], axis=1)
     never = cull_never(qbox)
     b[never, :3], b[never, 3:] = -np.inf, np.inf
