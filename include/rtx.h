@@ -205,6 +205,12 @@ int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
  * fma(float(q), scale, -(o - lo)) * (1/d), so that a CPU checker can replay the very same culling decisions.  No
  * counterpart in the reference (its KDTree.worldBox, kdtree.c:435, is never used by the traversal). */
 int rtx_cull_data_build(const rtx_scene_desc* desc, uint16_t* qbox6, float* info14);
+/* Second half of that seam (host only).  Cut-off nodes — inner nodes with an empty leaf for a child, 44 % of what KDTree_New
+ * (src/rt/accelerators/kdtree.c:405-444) builds — are folded into the step of their non-empty child on the device:
+ * flags[n] bit 0 = node n is never fetched (its plane, CheckHitInternalNode :501-570, is evaluated when its non-empty child is
+ * entered), bit 1 = node n carries its parent's plane and is entered without a box test of its own (its box is its parent's).
+ * n_nodes bytes. */
+int rtx_cull_node_flags(const rtx_scene_desc* desc, uint8_t* flags);
 
 /* ---- ray-level parity seam: batched Scene_ClosestHit (src/world/scene.h:12).
  * Host pointers, interleaved xyz.  dir need not be normalised: Ray_Make (src/rt/ray.c:3-16)

@@ -31,7 +31,7 @@ def lib():
         f32p, u32p, u8p, u64p = (C.POINTER(t) for t in (C.c_float, C.c_uint32, C.c_uint8, C.c_uint64))
         dp = C.POINTER(rtx_scene_desc)
         L.oracle_trace.argtypes = [dp, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
-        L.oracle_trace_culled.argtypes = [dp, C.POINTER(C.c_uint16), f32p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
+        L.oracle_trace_culled.argtypes = [dp, C.POINTER(C.c_uint16), f32p, u8p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
         L.oracle_render.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), f32p, u8p, u64p, C.c_int]
         L.oracle_camera_rays.argtypes = [C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
                                          f32p, f32p, u32p]
@@ -49,7 +49,7 @@ def _p(a, t):
 
 
 def trace(desc, origin, direction, unit_dir=False, cull=None):
-    """Scene_ClosestHit per ray.  cull = (qbox, info14) replays the GPU's subtree-box culling (checker mode)."""
+    """Scene_ClosestHit per ray.  cull = (qbox, info14[, node_flags]) replays the GPU's subtree-box culling (checker mode)."""
     o = np.ascontiguousarray(origin, np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
     n = len(o)
@@ -59,7 +59,8 @@ def trace(desc, origin, direction, unit_dir=False, cull=None):
     steps = np.zeros(n, np.uint32)
     qbox = np.ascontiguousarray(cull[0], np.uint16) if cull is not None else None
     info = np.ascontiguousarray(cull[1], np.float32) if cull is not None else None
-    rc = lib().oracle_trace_culled(desc, _p(qbox, C.c_uint16), _p(info, C.c_float), n, _p(o, C.c_float), _p(d, C.c_float), int(unit_dir), _p(out["prim_id"], C.c_uint32),
+    flags = np.ascontiguousarray(cull[2], np.uint8) if cull is not None and len(cull) > 2 else None
+    rc = lib().oracle_trace_culled(desc, _p(qbox, C.c_uint16), _p(info, C.c_float), _p(flags, C.c_uint8), n, _p(o, C.c_float), _p(d, C.c_float), int(unit_dir), _p(out["prim_id"], C.c_uint32),
                             _p(out["t"], C.c_float), _p(out["position"], C.c_float), _p(out["normal"], C.c_float),
                             _p(out["uv"], C.c_float), _p(out["front"], C.c_uint8), _p(vis, C.c_uint64),
                             _p(steps, C.c_uint32))

@@ -267,6 +267,8 @@ static void HitInfo_SetFaceNormal(HitInfo* hit, const Ray* ray, vec3 outwardNorm
 // device's own boxes (rtx_cull_data_build) and the device's own test, operation for operation.
 struct Cull {
     const uint16_t* qbox; // 6 per node: min x y z, max x y z on the 16-bit grid; min.x = 0xFFFF, max.x = 0: never cull
+    const uint8_t*  flags; // per node (rtx_cull_node_flags) or NULL; bit 1: the device enters this node without a box test of its
+                           // own (its parent is a cut-off node whose plane the device evaluates in this node's step)
     vec3            c;
     f32             ro2, kt;
     vec3            lo, scale; // grid x(q) = lo + q * scale
@@ -520,7 +522,7 @@ static bool CheckHitInternalNode(Scene* sc, u32 node, const Ray* ray, Prim* objH
 
 static bool CheckHitNextNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, HitInfo* hit, f32 tMax) // :458
 {
-    if (sc->cull && cull_node(sc->cull, node, tMax)) { // checker mode only, see struct Cull
+    if (sc->cull && !(sc->cull->flags && (sc->cull->flags[node] & 2u)) && cull_node(sc->cull, node, tMax)) { // checker mode only, see struct Cull
         sc->nCulled++;
         return false;
     }
@@ -1156,10 +1158,10 @@ static inline uint8_t LinearTosRGB(f32 channel)
 extern "C" int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* o, const float* dxyz, int unit_dir, uint32_t* pid, float* t,
                             float* pos, float* nrm, float* uv, uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
-    return oracle_trace_culled(desc, NULL, NULL, n, o, dxyz, unit_dir, pid, t, pos, nrm, uv, front, visits3, steps_per_ray);
+    return oracle_trace_culled(desc, NULL, NULL, NULL, n, o, dxyz, unit_dir, pid, t, pos, nrm, uv, front, visits3, steps_per_ray);
 }
 
-extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, size_t n, const float* o,
+extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, const uint8_t* node_flags, size_t n, const float* o,
                                    const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
                                    uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
@@ -1167,6 +1169,7 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* q
     Cull  cull;
     if (qbox6) {
         cull.qbox   = qbox6;
+        cull.flags  = node_flags;
         cull.c      = vec(info14[0], info14[1], info14[2]);
         cull.ro2    = info14[3];
         cull.kt     = info14[4];

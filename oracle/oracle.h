@@ -31,7 +31,7 @@ int oracle_trace(const rtx_scene_desc* desc, size_t n, const float* origin_xyz, 
 /* The same query with the GPU library's subtree-box culling replayed on the CPU (checker for DESIGN.md §5;
  * not part of the reference): qbox6 / info14 come from rtx_cull_data_build.  visits receives 4 counters
  * {inner, leaf, prim, culled}.  qbox6 == NULL: plain oracle_trace. */
-int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, size_t n,
+int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, const uint8_t* node_flags /* rtx_cull_node_flags, or NULL */, size_t n,
                         const float* origin_xyz, const float* dir_xyz, int unit_dir, uint32_t* prim_id, float* t,
                         float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face, uint64_t* visits,
                         uint32_t* steps_per_ray);

@@ -337,7 +337,9 @@ static void build_cull_data(const rtx_scene_desc* d, CullData& out)
     double c[3], R = 0.0;
     for (int a = 0; a < 3; a++) c[a] = 0.5 * (lo[a] + hi[a]), R += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
     R               = sqrt(R) + 1e-6;
-    const double RO = 3.0 * R, D = 1.01 * (RO + R), SAFETY = 1.25;
+    double ro_factor = 3.0;
+    if (const char* e = getenv("RTX_CULL_RO")) ro_factor = std::max(0.1, atof(e)); // experiments: culling radius in scene radii
+    const double RO = ro_factor * R, D = 1.01 * (RO + R), SAFETY = 1.25;
     std::vector<float> betas(T);
     for (int a = 0; a < 3; a++) out.c[a] = (float)c[a];
     out.ro2 = round_down(RO * RO * 0.999);
@@ -476,6 +478,67 @@ static void pack_box(const uint16_t* q, uint32_t w[3])
     for (int a = 0; a < 3; a++) w[a] = (uint32_t)q[3 + a] << 16 | q[a];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cut-off nodes folded into the step of their only real child.
+//
+// 44 % of the inner nodes KDTree_New builds cut empty space off: one child is an empty leaf.  Half of all node steps of a
+// walk are spent on them, and such a step can only do two things — clip tMax, or end the subtree's walk.  The culled
+// kernel therefore evaluates the plane of a cut-off node P (CheckHitInternalNode, kdtree.c:501-570, with one child known
+// to report nothing) at the head of the step of P's non-empty child X, and links P's parent straight to X: P is never
+// fetched and costs no step of its own.  One plane per record: X may carry P only if P carries none itself (a chain of k
+// cut-offs above a node keeps every other one).  Results are those of stepping through P — same comparisons, same
+// arithmetic; the only difference is that X is entered without a box test of its own (its box is P's box, which P's
+// parent tested), which the CPU replay follows through the flags (rtx_cull_node_flags).
+// ---------------------------------------------------------------------------------------------
+enum { NODE_ABSORBED = 1, NODE_CARRIES_PARENT = 2 };
+struct MergePlan {
+    std::vector<uint8_t>  flags;  // per node: NODE_ABSORBED | NODE_CARRIES_PARENT
+    std::vector<uint32_t> parent; // of a node that carries its parent's plane
+};
+
+static bool is_empty_leaf(const rtx_scene_desc* d, uint32_t n) { return (d->node_w1[n] >> 30) == 3u && d->node_w0[n] == 0u; }
+
+static void build_merge_plan(const rtx_scene_desc* d, MergePlan& mp) // the tree's shape has been validated
+{
+    const size_t N = d->n_nodes;
+    mp.flags.assign(N, 0);
+    mp.parent.assign(N, 0xFFFFFFFFu);
+    std::vector<uint32_t> st;
+    st.push_back(d->root_index);
+    while (!st.empty()) { // parents before children
+        const uint32_t n = st.back();
+        st.pop_back();
+        if ((d->node_w1[n] >> 30) == 3u) continue;
+        const uint32_t l = d->node_w1[n] & 0x3FFFFFFFu, r = n + 1;
+        const bool     el = is_empty_leaf(d, l), er = is_empty_leaf(d, r);
+        if (el != er && !(mp.flags[n] & NODE_CARRIES_PARENT)) { // a cut-off node that carries no plane itself: its real child takes it over
+            const uint32_t x = el ? r : l;
+            mp.flags[n] |= NODE_ABSORBED;
+            mp.flags[x] |= NODE_CARRIES_PARENT;
+            mp.parent[x] = n;
+        }
+        st.push_back(r), st.push_back(l);
+    }
+}
+
+static uint32_t merge_resolve(const rtx_scene_desc* d, const MergePlan& mp, uint32_t n) // the node a link to n leads to
+{
+    if (!(mp.flags[n] & NODE_ABSORBED)) return n;
+    const uint32_t l = d->node_w1[n] & 0x3FFFFFFFu;
+    return is_empty_leaf(d, l) ? n + 1 : l;
+}
+
+extern "C" int rtx_cull_node_flags(const rtx_scene_desc* d, uint8_t* flags)
+{
+    if (!flags) return fail(RTX_E_INVALID, "null argument");
+    int rc = validate_desc(d);
+    if (rc != RTX_OK) return rc;
+    MergePlan mp;
+    build_merge_plan(d, mp);
+    memcpy(flags, mp.flags.data(), mp.flags.size());
+    return RTX_OK;
+}
+
 extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint16_t* qbox6, float* info14)
 {
     if (!qbox6 || !info14) return fail(RTX_E_INVALID, "null argument");
@@ -533,19 +596,37 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         build_cull_data(d, cd);
         tm.lap("culling boxes");
         {
-            std::vector<uint4> n32(2 * (size_t)d->n_nodes, make_uint4(0, 0, 0, 0));
+            // 40-byte records: {w0, w1 (left link resolved), L.x, L.y | L.z, R.x, R.y, R.z | right link : 29, carried plane's
+            // axis : 2 (3 = none), side : 1 (1: this node is the carried parent's right child), carried plane's split}
+            MergePlan mp;
+            build_merge_plan(d, mp);
+            if (d->n_nodes >= (1u << 29)) {
+                rtx_scene_destroy(sc);
+                return fail(RTX_E_LIMIT, "more than 2^29 kd nodes");
+            }
+            std::vector<uint32_t> n40(NODE_WORDS * (size_t)d->n_nodes + 4, 0u); // + 16 bytes: the last record is read as 16 + 16 + 8
             parallel_ranges(d->n_nodes, [&](size_t i_lo, size_t i_hi) {
             for (size_t i = i_lo; i < i_hi; i++) {
-                uint32_t l[3] = {0, 0, 0}, r[3] = {0, 0, 0};
-                if ((d->node_w1[i] >> 30) != 3u) { // indices checked by validate_desc
-                    pack_box(&cd.q16[6 * (size_t)(d->node_w1[i] & 0x3FFFFFFFu)], l);
+                uint32_t l[3] = {0, 0, 0}, r[3] = {0, 0, 0}, w1 = d->node_w1[i], right = 0;
+                if ((w1 >> 30) != 3u) { // indices checked by validate_desc
+                    const uint32_t li = w1 & 0x3FFFFFFFu;
+                    pack_box(&cd.q16[6 * (size_t)li], l);
                     pack_box(&cd.q16[6 * ((size_t)i + 1)], r);
+                    w1    = (w1 & 0xC0000000u) | merge_resolve(d, mp, li);
+                    right = merge_resolve(d, mp, (uint32_t)i + 1);
                 }
-                n32[2 * (size_t)i]     = make_uint4(d->node_w0[i], d->node_w1[i], l[0], l[1]);
-                n32[2 * (size_t)i + 1] = make_uint4(l[2], r[0], r[1], r[2]);
+                uint32_t axis = 3u, side = 0u, split = 0u;
+                if (mp.flags[i] & NODE_CARRIES_PARENT) {
+                    const uint32_t pn = mp.parent[i];
+                    axis = d->node_w1[pn] >> 30, side = (i == (size_t)pn + 1) ? 1u : 0u, split = d->node_w0[pn];
+                }
+                uint32_t* w = &n40[NODE_WORDS * i];
+                w[0] = d->node_w0[i], w[1] = w1, w[2] = l[0], w[3] = l[1], w[4] = l[2], w[5] = r[0], w[6] = r[1], w[7] = r[2];
+                w[8] = right | axis << 29 | side << 31, w[9] = split;
             }
             });
-            UP(upload(sc, n32.data(), n32.size(), &S.nodes32));
+            UP(upload(sc, n40.data(), n40.size(), &S.nodes40));
+            S.root = merge_resolve(d, mp, d->root_index);
             pack_box(&cd.q16[6 * (size_t)d->root_index], S.root_q);
         }
         for (int a = 0; a < 3; a++) S.cull_c[a] = cd.c[a], S.cull_lo[a] = cd.lo[a], S.cull_scale[a] = cd.scale[a];
@@ -660,7 +741,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
     }
     tm.lap("the rest");
     S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
-    S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root = d->root_index;
+    S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root_literal = d->root_index;
     for (int i = 0; i < 6; i++) S.skybox_tex[i] = d->skybox_tex[i];
     UP(noalloc_scratch_address(sc)); // needs cull_useful (set above) to know which kernels this scene launches
 #undef UP
@@ -1034,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
                     // keep the six quotients in registers: without this the optimiser sinks the
                     // divisions behind the per-node axis select and redoes one per node visit
                     asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
-                    node   = S.root;
+                    node   = S.root_literal;
                     tMax   = RTX_INF;
                     sp     = 0;
                     inLeaf = false;
@@ -1368,7 +1449,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                             pRef  = HIT_PLANE | i;
                         }
                     }
-                    node  = S.root;
+                    node  = CULL ? S.root : S.root_literal;
                     tMax  = RTX_INF;
                     sp    = 0;
                     base  = 0;
@@ -1403,18 +1484,49 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         if (ranInner) {
             uint2    nd;
             uint4    qa = make_uint4(0, 0, 0, 0), qb = qa; // CULL: {w0, w1, L.x, L.y}, {L.z, R.x, R.y, R.z}: the children's boxes
+            uint2    qc = make_uint2(0, 0);                // CULL: {right link | carried plane's axis and side, its split}
+            bool     cut = false; // CULL: the cut-off node folded into this step ends the walk of its subtree
             if (CULL) {
-                qa = S.nodes32[2ull * node], qb = S.nodes32[2ull * node + 1];
-                // both halves requested before anything waits for the first (else the compiler sinks the boxes' loads
-                // below the leaf test: two trips to the cache per step)
-                asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w), "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+                const uint32_t* rec = S.nodes40 + (uint64_t)NODE_WORDS * node;
+                qa = *(const uint4*)rec, qb = *(const uint4*)(rec + 4), qc = *(const uint2*)(rec + 8);
+                // the whole record requested before anything waits for its first part (else the compiler sinks the boxes'
+                // loads below the leaf test: two trips to the cache per step)
+                asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w), "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w), "+v"(qc.x), "+v"(qc.y));
                 nd = make_uint2(qa.x, qa.y);
+                const uint32_t cax = (qc.x >> 29) & 3u;
+                if (cax != 3u) {
+                    // This node's parent P is a cut-off node — one child an empty leaf — that has no record of its own:
+                    // CheckHitInternalNode for P (kdtree.c:501-570), with the empty child's visit (no hit, :475-499) left out.
+                    if (COUNT) vis.inner++;
+                    const float split = __uint_as_float(qc.y);
+                    const bool  cx0 = cax == 0u, cx1 = cax == 1u;
+                    const float dA   = cx0 ? d.x : (cx1 ? d.y : d.z);
+                    const float oA   = cx0 ? o.x : (cx1 ? o.y : o.z);
+                    const float invA = cx0 ? inv.x : (cx1 ? inv.y : inv.z);
+                    const float oddA = cx0 ? odd.x : (cx1 ? odd.y : odd.z);
+                    const bool  par    = fabsf(dA) < RT_EPSILON; // :509
+                    const float tI     = split * invA - oddA;    // :518
+                    const float tMaxN  = minf_(tMax, tI);        // :519
+                    const bool  behind = tI < RT_EPSILON;        // :521
+                    const bool  both   = !par && !behind;        // :537
+                    const bool  ge      = oA >= split;
+                    const bool  tieSide = (oA + 100.0f * dA) >= split;
+                    const bool  goRight = (!par && behind && oA == split) ? tieSide : ge;
+                    const bool  here    = goRight == ((qc.x >> 31) != 0u); // the origin's side of P's plane is this node's side
+                    // here: this node is P's near child, walked with min(tMax, tI) (:546-549, :558-561); P's far child is empty.
+                    // else: the near child is the empty leaf; this node is walked — with the outer tMax — only if the plane
+                    // lies within the range (:551, :563), else P reports no hit
+                    cut  = !here && !(both && tMaxN == tI);
+                    tMax = (here && both) ? tMaxN : tMax;
+                }
             } else {
                 nd = S.nodes[node];
             }
             const uint32_t type = nd.y >> 30;
             const uint32_t idx  = nd.y & 0x3FFFFFFFu;
-            if (type == 3u) {
+            if (CULL && cut) {
+                pop = true;
+            } else if (type == 3u) {
                 if (COUNT) vis.leaf++;
                 if (nd.x != 0u) {
                     state   = ST_LEAF;
@@ -1432,7 +1544,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
             } else {
                 if (COUNT) vis.inner++;
                 const float    split = __uint_as_float(nd.x);
-                const uint32_t right = node + 1;
+                const uint32_t right = CULL ? (qc.x & 0x1FFFFFFFu) : node + 1; // (CULL: links skip the folded cut-off nodes)
                 const bool     ax0 = type == 0u, ax1 = type == 1u;
                 const float    dA   = ax0 ? d.x : (ax1 ? d.y : d.z);
                 const float    oA   = ax0 ? o.x : (ax1 ? o.y : o.z);
@@ -1676,7 +1788,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                         pRef  = HIT_PLANE | i;
                     }
                 }
-                node  = S.root;
+                node  = CULL ? S.root : S.root_literal;
                 tMax  = RTX_INF;
                 sp    = 0;
                 base  = 0;
@@ -1782,7 +1894,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(8))
                         // inside the root's box, but perhaps outside both of its children's (the first split of these
                         // scenes has the model on one side and the light on the other): the closest-hit kernel's first
                         // step would then find nothing to descend into and nothing to push, whatever tMax it tests with
-                        const uint4 qa = S.nodes32[2ull * S.root], qb = S.nodes32[2ull * S.root + 1];
+                        const uint32_t* rec = S.nodes40 + (uint64_t)NODE_WORDS * S.root; // (a cut-off plane carried by the root only ever removes rays)
+                        const uint4     qa = *(const uint4*)rec, qb = *(const uint4*)(rec + 4);
                         none = (qa.y >> 30) != 3u && box_missed(S, qa.z, qa.w, qb.x, o2, inv2, RTX_INF) && box_missed(S, qb.y, qb.z, qb.w, o2, inv2, RTX_INF);
                     }
                     if (none) {

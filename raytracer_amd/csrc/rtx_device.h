@@ -26,6 +26,8 @@
 #define TRI_WAIT 1
 #endif
 
+#define NODE_WORDS 10 // dwords per record of the culled kernel's node pool
+
 #define DEV __device__ __forceinline__
 
 // hit reference produced by the closest-hit kernel
@@ -39,12 +41,14 @@
 // ---------------------------------------------------------------------------------------------
 struct SceneDev {
     const uint2*    nodes;    // {w0 = split bits | len, w1 = type<<30 | index}
-    // culled kernel (k_trace_flat<.., CULL>): 32 B per node, the node and the conservative boxes of BOTH children,
-    // so that a child the ray cannot reach is never fetched:
-    //   [0] = {w0, w1, L.x, L.y}   [1] = {L.z, R.x, R.y, R.z}      L / R = left (index in w1) / right (node + 1) child
+    // culled kernel (k_trace_flat<.., CULL>): NODE_WORDS dwords per node — the node, the conservative boxes of BOTH children
+    // (a child the ray cannot reach is never fetched) and, where the node's parent is a cut-off node folded into this
+    // node's step, that parent's plane (rt_hip.hip, build_merge_plan):
+    //   [0..3] = {w0, w1, L.x, L.y}   [4..7] = {L.z, R.x, R.y, R.z}   [8] = right link : 29 | plane axis : 2 (3 = none) | side : 1
+    //   [9] = plane split.   L / R = left (link in w1) / right child; links skip the folded cut-off nodes.
     // a box is three words, one per axis, max << 16 | min, on the 16-bit grid  coordinate = cull_lo + q * cull_scale;
     // min.x = 0xFFFF with max.x = 0: never cull.  root_q = the root's box.
-    const uint4*    nodes32;
+    const uint32_t* nodes40;
     uint32_t        root_q[3];
     float           cull_c[3], cull_ro2; // culling is applied to rays whose origin lies within sqrt(ro2) of c
     float           cull_kt;             // a subtree's tMax is stretched by this factor (>= 1) in the box test
@@ -68,7 +72,9 @@ struct SceneDev {
     const rtx_material*     mats;
     const rtx_texture_desc* tex;
     const float*            tex_data;
-    uint32_t                n_nodes, n_refs, n_tris, n_spheres, n_planes, n_materials, n_textures, root;
+    uint32_t                n_nodes, n_refs, n_tris, n_spheres, n_planes, n_materials, n_textures;
+    uint32_t                root;         // culled kernel: where a link to the root leads (the root itself unless it is a folded cut-off node)
+    uint32_t                root_literal; // literal walk: desc.root_index
     int32_t                 skybox_tex[6];
 };
 
@@ -401,7 +407,7 @@ DEV void closest_hit(const SceneDev& S, const RayD& ray, uint32_t& ref, float& t
 {
     uint2    stk[RTX_STACK];
     int      sp   = 0;
-    uint32_t node = S.root;
+    uint32_t node = S.root_literal;
     float    tMax = RTX_INF;
 
     ref  = HIT_MISS;

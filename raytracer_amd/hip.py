@@ -19,7 +19,7 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags"]
 RTX_NOALLOC_MAX_RAYS = 1 << 18
 
 _lib = None
@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
     sig("rtx_scene_destroy", C.c_int, vp)
     sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
     sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), C.POINTER(C.c_uint16), f32p)
+    sig("rtx_cull_node_flags", C.c_int, C.POINTER(rtx_scene_desc), u8p)
     sig("rtx_trace_closest", C.c_int, vp, C.c_size_t, f32p, f32p, u32p, f32p, f32p, f32p, f32p, u8p,
         C.POINTER(rtx_stats), C.c_uint32)
     sig("rtx_trace_closest_device", C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp)
@@ -144,11 +145,14 @@ def make_params(width, height, spp, max_depth, seed=(1, 2), sample_range=None, b
 
 def cull_data(desc):
     """Quantised conservative subtree boxes + culling constants of a scene (host-side preprocessing of
-    librt_hip.so, no device needed): (qbox[n_nodes, 6] u16, info[14] f32), see rtx_cull_data_build."""
+    librt_hip.so, no device needed): (qbox[n_nodes, 6] u16, info[14] f32, node_flags[n_nodes] u8), see rtx_cull_data_build
+    and rtx_cull_node_flags."""
     qbox = np.zeros((desc.contents.n_nodes, 6), np.uint16)
     info = np.zeros(14, np.float32)
+    flags = np.zeros(desc.contents.n_nodes, np.uint8)
     _check(lib().rtx_cull_data_build(desc, _p(qbox, C.c_uint16), _p(info, C.c_float)))
-    return qbox, info
+    _check(lib().rtx_cull_node_flags(desc, _p(flags, C.c_uint8)))
+    return qbox, info, flags
 
 
 def cull_never(qbox):

@@ -42,7 +42,7 @@ def test_culled_equals_literal_on_awkward_rays(built_scenes):
     sc = built_scenes("teapot")
     cull = hip.cull_data(sc.desc)
     info = cull[1]
-    boxes = hip.cull_boxes_world(*cull).astype(np.float32)
+    boxes = hip.cull_boxes_world(cull[0], cull[1]).astype(np.float32)
     rng = np.random.default_rng(7)
     n = 20000
     node = rng.integers(0, len(boxes), n)
@@ -83,7 +83,7 @@ def test_boxes_contain_their_primitives(built_scenes):
     """Structure of the cull data: a parent's box contains both children's, a leaf's box its primitives' vertices."""
     sc = built_scenes("teapot")
     d = sc.desc.contents
-    qbox, info = hip.cull_data(sc.desc)
+    qbox, info, _ = hip.cull_data(sc.desc)
     boxes = hip.cull_boxes_world(qbox, info)
     w0 = np.ctypeslib.as_array(d.node_w0, (d.n_nodes,))
     w1 = np.ctypeslib.as_array(d.node_w1, (d.n_nodes,))
@@ -152,11 +152,11 @@ def test_boxes_do_not_depend_on_the_node_numbering(built_scenes):
     d2.node_w0 = p0.ctypes.data_as(C.POINTER(C.c_uint32))
     d2.node_w1 = p1.ctypes.data_as(C.POINTER(C.c_uint32))
     d2.root_index = int(new_of_old[d.root_index])
-    q1, i1 = hip.cull_data(sc.desc)
-    q2, i2 = hip.cull_data(C.pointer(d2))
-    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and np.array_equal(q2[new_of_old], q1)
+    q1, i1, f1 = hip.cull_data(sc.desc)
+    q2, i2, f2 = hip.cull_data(C.pointer(d2))
+    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and np.array_equal(q2[new_of_old], q1) and np.array_equal(f2[new_of_old], f1)
     rays = golden("trace_teapot.npz")["rays"][:4000]
-    _same(O.trace(C.pointer(d2), rays[:, :3], rays[:, 3:], cull=(q2, i2)), O.trace(sc.desc, rays[:, :3], rays[:, 3:]))
+    _same(O.trace(C.pointer(d2), rays[:, :3], rays[:, 3:], cull=(q2, i2, f2)), O.trace(sc.desc, rays[:, :3], rays[:, 3:]))
 
 
 def _desc_with_nodes(d, w0, w1, root=None, max_depth=None):

@@ -119,9 +119,11 @@ def test_culled_walk_replays_on_the_cpu(built_scenes, device_scenes, scene):
         assert same_bits(cul[k], lit[k]), k
     want = O.trace(sc.desc, rec["o"], rec["d"], unit_dir=True, cull=hip.cull_data(sc.desc))["visits"]
     s = cul["stats"]
-    # the kernel tests a child's box at its parent — a far child's even when the near side then reports a hit — so it
-    # may count more culled boxes than the replay, which tests on entry; the nodes and primitives visited are the same
-    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == want.tolist()[:3] and s["visits_culled"] >= want[3]
+    # The nodes and primitives visited are the same (a cut-off node folded into its child's step counts as the inner visit
+    # it stands for).  The numbers of culled boxes are not comparable: the kernel tests a child's box at its parent — a far
+    # child's even when the near side then reports a hit — and never meets the empty child of a folded cut-off node, which
+    # the replay enters and culls.
+    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == want.tolist()[:3] and s["visits_culled"] > 0 and want[3] > 0
     assert s["visits_inner"] + s["visits_leaf"] + s["visits_culled"] < 0.5 * len(rec) * 100  # and it does cull
 
 
@@ -513,7 +515,7 @@ def test_awkward_rays_match_the_oracle(built_scenes, device_scenes, scene):
     the culling boxes, origins far outside, non-unit, infinite and NaN directions: same ids from the kernel as from
     the CPU restatement of the reference's recursion, same bits wherever the hit is finite, and no fault."""
     sc, ds = built_scenes(scene), device_scenes(scene)
-    qbox, info = hip.cull_data(sc.desc)
+    qbox, info, _ = hip.cull_data(sc.desc)
     boxes = hip.cull_boxes_world(qbox, info)
     boxes = boxes[np.isfinite(boxes).all(axis=1)].astype(np.float32)
     rng = np.random.default_rng(17)
