@@ -36,9 +36,11 @@ pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_AC
 rm -rf "$OUT/trace"
 # HBM-side traffic of the closest-hit kernel per launch (timed frame = the last 8 k_trace dispatches):
 # FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
-out = sys.argv[1]
+out, tag = sys.argv[1], sys.argv[2]
+bench = json.loads(open("%s/bench.json" % out).read().strip().splitlines()[-1])
+traced = bench["config"]["rays_per_frame"] - bench["config"]["rays_answered_in_shade"]  # rays handed to the closest-hit kernel
 def table(name):
     lines = open("%s/pmc_%s.txt" % (out, name)).read().splitlines()
     cols = lines[0].split()[1:]
@@ -59,7 +61,12 @@ d = {"workload": "dragon1 1920x1080 64spp d8", "hbm_bytes_per_launch": sum(per_l
      "l2_hit_rate": sum(tcc["TCC_HIT_sum"]) / sum(tcc["TCC_REQ_sum"]),
      "valu_busy": sum(4.0 * x for x in sq["SQ_INSTS_VALU"]) / sum(simd_cycles),
      "valu_busy_per_launch": [4.0 * x / c for x, c in zip(sq["SQ_INSTS_VALU"], simd_cycles)],
-     "valu_lane_utilisation": sum(sq["SQ_THREAD_CYCLES_VALU"]) / (64.0 * sum(sq["SQ_ACTIVE_INST_VALU"]))}
+     "valu_lane_utilisation": sum(sq["SQ_THREAD_CYCLES_VALU"]) / (64.0 * sum(sq["SQ_ACTIVE_INST_VALU"])),
+     # per depth (= per launch of the timed frame): what VERDICT r01 asked to keep
+     "per_launch": {"SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_THREAD_CYCLES_VALU": sq["SQ_THREAD_CYCLES_VALU"], "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"],
+                    "lane_utilisation": [t / (64.0 * a) for t, a in zip(sq["SQ_THREAD_CYCLES_VALU"], sq["SQ_ACTIVE_INST_VALU"])]},
+     "valu_insts_per_frame": sum(sq["SQ_INSTS_VALU"]), "rays_traced_per_frame": traced,
+     "valu_insts_per_traced_ray": sum(sq["SQ_INSTS_VALU"]) / traced, "measured_at": tag}
 json.dump(d, open("%s/traffic.json" % out, "w"), indent=1)
 print(json.dumps({k: v for k, v in d.items() if not isinstance(v, list)}, indent=1))
 PY
