@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
 // predicated store), and the leaf keeps the NEXT leaf reference in flight while testing the
 // current primitive.
 // ---------------------------------------------------------------------------------------------
-enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2, ST_SHADE = 3 };
+enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2, ST_SHADE = 3, ST_DONE = 4 }; // DONE: walk finished, hit record not written yet
 // One wave per block: the waves share nothing, and a block's LDS and wave slots come free the moment ITS wave
 // has finished its last ray — with 4-wave blocks the slowest of four decided, which kept the next kernel's
 // blocks (the other lane of rtx_render_device, or simply the shade pass) out of the CU during the tail.
@@ -1385,8 +1385,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     };
 
     for (;;) {
-        const uint64_t idle  = __ballot(state == ST_IDLE);
+        // (a lane whose walk has finished keeps its hit — DONE — until the wave next refills or ends: the record's four
+        // stores and the merge with the unbounded list then run for many lanes at once instead of for one or two)
+        const uint64_t idle  = __ballot(state == ST_IDLE || state == ST_DONE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
+        if ((exhausted && nidle == 64u) || (!exhausted && nidle >= refill_min)) {
+            if (!TAIL && state == ST_DONE) {
+                write_hit(best, bestT, bu, bv);
+                state = ST_IDLE;
+            }
+        }
         if (exhausted && nidle == 64u) break;
         if (!exhausted && nidle >= refill_min) {
             if (next >= end) {
@@ -1726,8 +1734,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 if (pRef != HIT_MISS && (best == HIT_MISS || pBest < bestT)) best = pRef, bestT = pBest, bu = 0.0f, bv = 0.0f;
                 state = ST_SHADE;
             } else {
-                write_hit(best, bestT, bu, bv);
-                state = ST_IDLE;
+                state = ST_DONE;
             }
         }
         if (TAIL && doShade && state == ST_SHADE) {
