@@ -196,6 +196,14 @@ int         rtx_device_count(int* count);
 /* ---- scene hand-over: replaces the pointer the render workers read (ctx->scene,
  *      src/rt/renderer.c:151) with device-resident pools ---- */
 int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
+/* The same with flags.  Textures are kept on the device in a compact, LOSSLESS form where their values allow it
+ * (SURVEY §8f-3): a texture whose channels take at most 256 distinct binary32 values — every imported BMP, whose texels
+ * are sRGBToLinear(byte / 255) (src/gfx/texture.c:15-47) — is stored as 3 bytes per texel + a 256-entry palette of the
+ * original bit patterns, so Texture_ColorAt / Skybox_ColorAt (src/gfx/texture.c:88-95, src/world/skybox.c:66-134)
+ * return exactly the floats of the f32 image at a quarter of the footprint.  RTX_SCENE_F32_TEXTURES keeps every
+ * texture as handed over (the tests compare the two). */
+#define RTX_SCENE_F32_TEXTURES 1u
+int rtx_scene_create_ex(const rtx_scene_desc* desc, int device, uint32_t flags, rtx_scene** out);
 int rtx_scene_destroy(rtx_scene* scene);
 int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);
 /* Parity seam for the culled walk (host only, needs no device): the conservative, quantised subtree

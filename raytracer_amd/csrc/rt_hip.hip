@@ -555,9 +555,13 @@ extern "C" int rtx_cull_data_build(const rtx_scene_desc* d, uint16_t* qbox6, flo
 
 static int noalloc_scratch_address(rtx_scene* sc);
 
-extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene** out)
+extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene** out) { return rtx_scene_create_ex(d, device, 0u, out); }
+
+extern "C" int rtx_scene_create_ex(const rtx_scene_desc* d, int device, uint32_t flags, rtx_scene** out)
 {
     if (!out) return fail(RTX_E_INVALID, "null output");
+    if (flags & ~RTX_SCENE_F32_TEXTURES) return fail(RTX_E_INVALID, "unknown scene flags 0x%x", flags);
+    const bool compact_textures = !(flags & RTX_SCENE_F32_TEXTURES);
     *out = nullptr;
     int n = 0, rc;
     if ((rc = rtx_device_count(&n)) != RTX_OK) return rc;
@@ -721,8 +725,52 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
         UP(upload(sc, pl.data(), pl.size(), &S.plane));
     }
     UP(upload(sc, d->materials, d->n_materials, &S.mats));
-    UP(upload(sc, d->textures, d->n_textures, &S.tex));
-    UP(upload(sc, d->tex_data, (size_t)d->tex_texels * 3, &S.tex_data));
+    {
+        // Textures: PAL8 where a texture's values allow it (see TexDev), else the floats as they are.  Only what is kept
+        // as f32 goes into the device's float pool.
+        std::vector<TexDev>  td(d->n_textures);
+        std::vector<float>   f32pool, pal;
+        std::vector<uint8_t> bytes;
+        for (uint32_t k = 0; k < d->n_textures; k++) {
+            const rtx_texture_desc& t = d->textures[k];
+            const uint64_t texels = (uint64_t)t.width * t.height;
+            const uint32_t* src = (const uint32_t*)(d->tex_data + 3 * t.offset); // bit patterns: -0, NaN payloads stay what they are
+            td[k].width = t.width, td[k].height = t.height, td[k].fmt = TEX_F32, td[k].pal = 0;
+            std::vector<uint32_t> values; // distinct bit patterns, sorted
+            bool paletted = compact_textures && texels >= 64;
+            if (paletted) {
+                uint32_t last = ~src[0];
+                for (uint64_t i = 0; i < 3 * texels && paletted; i++) {
+                    const uint32_t v = src[i];
+                    if (v == last) continue; // runs of equal values are the common case
+                    last = v;
+                    auto it = std::lower_bound(values.begin(), values.end(), v);
+                    if (it == values.end() || *it != v) {
+                        if (values.size() == 256) paletted = false;
+                        else values.insert(it, v);
+                    }
+                }
+            }
+            if (paletted) {
+                td[k].fmt = TEX_PAL8, td[k].pal = (uint32_t)pal.size(), td[k].offset = bytes.size();
+                pal.resize(pal.size() + 256, 0.0f);
+                memcpy(&pal[td[k].pal], values.data(), values.size() * 4);
+                const size_t b0 = bytes.size();
+                bytes.resize(b0 + 3 * texels);
+                parallel_ranges(3 * texels, [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi; i++) bytes[b0 + i] = (uint8_t)(std::lower_bound(values.begin(), values.end(), src[i]) - values.begin());
+                });
+            } else {
+                td[k].offset = f32pool.size() / 3;
+                f32pool.insert(f32pool.end(), d->tex_data + 3 * t.offset, d->tex_data + 3 * (t.offset + texels));
+            }
+        }
+        bytes.resize(bytes.size() + 4, 0); // (a lookup reads single bytes; padding keeps the pool non-empty)
+        UP(upload(sc, td.data(), td.size(), &S.tex));
+        UP(upload(sc, f32pool.data(), f32pool.size(), &S.tex_data));
+        UP(upload(sc, bytes.data(), bytes.size(), &S.tex_bytes));
+        UP(upload(sc, pal.data(), pal.size(), &S.tex_pal));
+    }
     {
         std::vector<uint4> tab(8 * 256);
         for (int k = 0; k < 8; k++)

@@ -39,6 +39,17 @@
 // ---------------------------------------------------------------------------------------------
 // device-resident scene (built by rtx_scene_create from rtx_scene_desc)
 // ---------------------------------------------------------------------------------------------
+// A texture on the device.  F32: 3 floats per texel in tex_data, as handed over.  PAL8 (the compact texture
+// format): a texture whose channels take at most 256 distinct binary32 values — every imported BMP does: its texels are
+// sRGBToLinear(byte / 255) (src/gfx/texture.c:15-47, src/gfx/color.c:7-16) — is kept as 3 bytes per texel plus that palette.
+// The palette holds the original bit patterns, so a lookup returns exactly what the f32 texture would: 4x smaller and lossless.
+enum { TEX_F32 = 0, TEX_PAL8 = 1 };
+struct TexDev {
+    uint32_t width, height;
+    uint64_t offset; // F32: first texel in tex_data; PAL8: first byte in tex_bytes
+    uint32_t fmt, pal; // PAL8: first entry of the texture's palette in tex_pal
+};
+
 struct SceneDev {
     const uint2*    nodes;    // {w0 = split bits | len, w1 = type<<30 | index}
     // culled kernel (k_trace_flat<.., CULL>): NODE_WORDS dwords per node — the node, the conservative boxes of BOTH children
@@ -70,7 +81,9 @@ struct SceneDev {
     const uint32_t* sph_obj;
     const float*    plane; // 8 floats per plane: n.xyz p.xyz mat(bits) 0
     const rtx_material*     mats;
-    const rtx_texture_desc* tex;
+    const TexDev*           tex;
+    const uint8_t*          tex_bytes; // palettised textures: 3 palette indices per texel
+    const float*            tex_pal;   // their palettes, 256 entries each
     const float*            tex_data;
     uint32_t                n_nodes, n_refs, n_tris, n_spheres, n_planes, n_materials, n_textures;
     uint32_t                root;         // culled kernel: where a link to the root leads (the root itself unless it is a folded cut-off node)
@@ -586,13 +599,19 @@ DEV uint32_t hit_prim_id(const SceneDev& S, uint32_t ref)
 DEV f3 Texture_ColorAt(const SceneDev& S, int32_t tex, float u, float v)
 {
     if (tex < 0) return mk3(0.0f, 0.0f, 0.0f);
-    const rtx_texture_desc td = S.tex[tex];
+    const TexDev td = S.tex[tex];
     // (size_t)(st.x * (width-1)); the reference has no clamp (UB outside [0,1]) — clamp here
     float    fx = u * (float)(td.width - 1);
     float    fy = (1.0f - v) * (float)(td.height - 1);
     uint32_t xx = fx > 0.0f ? (uint32_t)fminf(fx, (float)(td.width - 1)) : 0u;
     uint32_t yy = fy > 0.0f ? (uint32_t)fminf(fy, (float)(td.height - 1)) : 0u;
-    const float* p = S.tex_data + 3ull * (td.offset + (uint64_t)yy * td.width + xx);
+    const uint64_t texel = (uint64_t)yy * td.width + xx;
+    if (td.fmt == TEX_PAL8) {
+        const uint8_t* b   = S.tex_bytes + td.offset + 3ull * texel;
+        const float*   pal = S.tex_pal + td.pal;
+        return mk3(pal[b[0]], pal[b[1]], pal[b[2]]);
+    }
+    const float* p = S.tex_data + 3ull * (td.offset + texel);
     return mk3(p[0], p[1], p[2]);
 }
 

@@ -19,7 +19,8 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex"]
+RTX_SCENE_F32_TEXTURES = 1
 RTX_NOALLOC_MAX_RAYS = 1 << 18
 
 _lib = None
@@ -61,6 +62,7 @@ def lib() -> C.CDLL:
     sig("rtx_last_error", C.c_char_p)
     sig("rtx_device_count", C.c_int, C.POINTER(C.c_int))
     sig("rtx_scene_create", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.POINTER(vp))
+    sig("rtx_scene_create_ex", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.c_uint32, C.POINTER(vp))
     sig("rtx_scene_destroy", C.c_int, vp)
     sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
     sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), C.POINTER(C.c_uint16), f32p)
@@ -172,9 +174,9 @@ def cull_boxes_world(qbox, info):
 class DeviceScene:
     """rtx_scene handle (one per scene and device)."""
 
-    def __init__(self, desc, device=0):
+    def __init__(self, desc, device=0, flags=0):
         self.handle = C.c_void_p()
-        _check(lib().rtx_scene_create(desc, device, C.byref(self.handle)))
+        _check(lib().rtx_scene_create_ex(desc, device, flags, C.byref(self.handle)))
         self.device = device
 
     def close(self):

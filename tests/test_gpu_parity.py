@@ -577,3 +577,25 @@ def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_sce
     assert ref[2]["rays_early_miss"] == 0 and out["traced_passes"][2]["rays_early_miss"] == 0
     if scene in ("dragon1", "teapot"):  # open scenes on a ground plane: a good part of the bounce rays leaves at once
         assert out["early"][2]["rays_early_miss"] > 0.1 * ref[2]["rays_total"]
+
+
+def test_compact_textures_are_lossless(built_scenes, device_scenes):
+    """SURVEY §8f-3, compact texture formats.  A texture whose channels take at most 256 distinct values (every imported
+    BMP: sRGBToLinear(byte / 255), texture.c:15-47) lives on the device as 3 bytes per texel + a palette of the original
+    bit patterns.  Same lookups and the same frames, bit for bit, as with the f32 images (RTX_SCENE_F32_TEXTURES), at about a
+    quarter of the texture footprint; the reference's own Skybox_ColorAt outputs still match (test_skybox_lookup_exact runs
+    on the compact scene)."""
+    sc = built_scenes("pear")  # 6 x 256^2 cube map + a 512^2 diffuse map, all from BMPs
+    compact = device_scenes("pear")
+    with hip.DeviceScene(sc.desc, 0, flags=hip.RTX_SCENE_F32_TEXTURES) as plain:
+        d = sc.desc.contents
+        tex_f32 = 12 * d.tex_texels
+        assert plain.device_bytes() - compact.device_bytes() > 0.7 * tex_f32  # 12 -> 3 bytes per texel (+ palettes)
+        rng = np.random.default_rng(3)
+        dirs = rng.normal(size=(20000, 3)).astype(np.float32)
+        assert same_bits(compact.skybox_color(dirs), plain.skybox_color(dirs))
+        g = golden("sky_pear.npz")
+        assert same_bits(plain.skybox_color(g["dirs"]), g["rgb"])
+        p = hip.make_params(200, 112, 4, 16, seed=(5, 9))
+        a, b = compact.render(sc.rtx_camera(), p), plain.render(sc.rtx_camera(), p)
+        assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1]) and a[2]["rays_at_depth"] == b[2]["rays_at_depth"]
