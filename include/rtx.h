@@ -193,6 +193,15 @@ int         rtx_abi_version(void);
 const char* rtx_last_error(void);
 int         rtx_device_count(int* count);
 
+/* ---- tuning knobs.  The render loop's switches (most exist so that a test can render a frame both ways and compare the
+ * bits; none changes a result) live in one process-wide table: OVERLAP, SORT_DEPTH, SORT_MIN, SORT_EVERY, TAIL_MAX,
+ * TAIL_SHADE_MIN, JUMP_TABLE, RAYGEN_LEAN, EARLY_MISS, FAST_DIV, BAND_TILES, TRACE_CHUNK.  The environment
+ * (RTX_<NAME>) is read ONCE, at first use, for the defaults; no entry point reads the environment per call.  Set a knob
+ * only while no call is in flight.  No counterpart in the reference (its switches are compile-time, src/common/config.h). ---- */
+int  rtx_tune_set(const char* name, long long value);
+int  rtx_tune_get(const char* name, long long* value);
+void rtx_tune_reset(void); /* back to the defaults (built-in, or RTX_<NAME> as it was at first use) */
+
 /* ---- scene hand-over: replaces the pointer the render workers read (ctx->scene,
  *      src/rt/renderer.c:151) with device-resident pools ---- */
 int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);

@@ -61,6 +61,81 @@ static int fail(int code, const char* fmt, ...)
                                           __FILE__, __LINE__);                                               \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// Tuning knobs.  Every switch the render loop has — most exist so that a test can render a frame both ways and compare
+// the bits — lives in ONE process-wide table.  The environment (RTX_<NAME>) is read once, when the table is first used,
+// and only sets the defaults; after that a call's behaviour depends on its arguments and on rtx_tune_set, never on the
+// environment of the moment.  Change a knob only while no call is in flight.
+// ---------------------------------------------------------------------------------------------
+#ifndef TAIL_MAX_DEFAULT
+#define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
+#endif
+enum { K_OVERLAP, K_SORT_DEPTH, K_SORT_MIN, K_SORT_EVERY, K_TAIL_MAX, K_TAIL_SHADE_MIN, K_JUMP_TABLE, K_RAYGEN_LEAN, K_EARLY_MISS, K_FAST_DIV,
+       K_BAND_TILES, K_TRACE_CHUNK, K_COUNT };
+struct Knob {
+    const char* name;
+    long long   dflt, value;
+};
+static Knob g_knobs[K_COUNT] = {
+    {"OVERLAP", 0, 0},            // 1..3: the assigned pixels go through the bounce loop as 2..4 parts on as many streams
+    {"SORT_DEPTH", 2, 0},         // bin the queues that feed depth >= this; 0 = never
+    {"SORT_MIN", 2500000, 0},     // ... if they hold at least this many rays
+    {"SORT_EVERY", 1, 0},         // ... every k-th eligible depth
+    {"TAIL_MAX", TAIL_MAX_DEFAULT, 0}, // longest queue handed to the tail launch; 0 = never
+    {"TAIL_SHADE_MIN", 16, 0},    // lanes that wait before the tail launch shades in place
+    {"JUMP_TABLE", 1, 0},         // 0: the literal 128-step seed jump in raygen
+    {"RAYGEN_LEAN", 1, 0},        // 0: raygen stores whole path records
+    {"EARLY_MISS", 1, 0},         // 0: every bounce ray goes through the closest-hit kernel
+    {"FAST_DIV", 1, 0},           // 0: plain divisions in the index decode
+    {"BAND_TILES", 1, 0},         // 0: 32 x 32 path tiles under the band split too
+    {"TRACE_CHUNK", 0, 0},        // rays per work grab of the closest-hit kernel; 0 = by queue length
+};
+static std::once_flag g_knobs_once;
+static void knobs_init()
+{
+    std::call_once(g_knobs_once, [] {
+        for (Knob& k : g_knobs) {
+            char env[64];
+            snprintf(env, sizeof env, "RTX_%s", k.name);
+            const char* e = getenv(env);
+            k.dflt  = e ? atoll(e) : k.dflt; // the environment at load time sets the default
+            k.value = k.dflt;
+        }
+    });
+}
+static long long knob(int k)
+{
+    knobs_init();
+    return g_knobs[k].value;
+}
+static Knob* find_knob(const char* name)
+{
+    knobs_init();
+    if (name)
+        for (Knob& k : g_knobs)
+            if (!strcmp(k.name, name)) return &k;
+    return nullptr;
+}
+extern "C" int rtx_tune_set(const char* name, long long value)
+{
+    Knob* k = find_knob(name);
+    if (!k) return fail(RTX_E_INVALID, "unknown tuning knob '%s'", name ? name : "(null)");
+    k->value = value;
+    return RTX_OK;
+}
+extern "C" int rtx_tune_get(const char* name, long long* value)
+{
+    Knob* k = find_knob(name);
+    if (!k || !value) return fail(RTX_E_INVALID, "unknown tuning knob '%s'", name ? name : "(null)");
+    *value = k->value;
+    return RTX_OK;
+}
+extern "C" void rtx_tune_reset(void)
+{
+    knobs_init();
+    for (Knob& k : g_knobs) k.value = k.dflt;
+}
+
 extern "C" int         rtx_abi_version(void) { return RTX_ABI_VERSION; }
 extern "C" const char* rtx_last_error(void) { return g_err; }
 
@@ -173,9 +248,6 @@ extern "C" int rtx_scene_device_bytes(const rtx_scene* sc, uint64_t* bytes)
 
 #ifndef TAIL_WAVES
 #define TAIL_WAVES 4 // waves per SIMD the tail kernel is compiled for (128 VGPRs: the shading code spills 26 values)
-#endif
-#ifndef TAIL_MAX_DEFAULT
-#define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
 #define EARLY_COUNTERS (8 * RTX_MAX_DEPTH) // after the TAIL_COUNTERS: [RTX_MAX_DEPTH * k + d]: rays of depth d answered in the shade pass before
 #define TAIL_COUNTERS 160 // [80 + 8 k]: paths shaded by k_shade, spread over 8 counters; u64 after the lanes' counters: rays started per depth by the tail kernel [RTX_MAX_DEPTH], paths it shaded
@@ -869,7 +941,7 @@ struct FrameGeom {
 static void geom_finish(FrameGeom& g)
 {
     g.fast = 0;
-    if (getenv("RTX_FAST_DIV") && atoi(getenv("RTX_FAST_DIV")) == 0) return; // the tests compare the two
+    if (knob(K_FAST_DIV) == 0) return; // the tests compare the two
     if ((uint64_t)g.width * g.height >= (1ull << 32) || g.n_samples == 0 || g.width == 0) return;
     g.fd_ns   = fastdiv_gen(g.n_samples);
     g.fd_w    = fastdiv_gen(g.width);
@@ -2319,6 +2391,11 @@ struct DevBuf { // RAII device buffer for the host-pointer entry points
     template <typename T> T* as() { return (T*)p; }
 };
 
+static bool trace_variant_forced() // RTX_TRACE_VARIANT given: the scene's own choice between culled and literal is overridden
+{
+    static const bool f = getenv("RTX_TRACE_VARIANT") != nullptr;
+    return f;
+}
 static int trace_variant()
 {
     // 0: one ray per thread, 1: persistent (nested loops), 2: persistent flat state machine,
@@ -2336,7 +2413,7 @@ static int trace_variant()
 static bool tail_capable(const rtx_scene* sc, bool literal)
 {
     const int  tv      = trace_variant();
-    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
+    const bool no_cull = literal || (!trace_variant_forced() && !sc->cull_useful);
     const int  variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
     return variant >= 4;
 }
@@ -2354,7 +2431,7 @@ struct TraceKernel {
 static TraceKernel pick_trace_kernel(const rtx_scene* sc, bool count, bool literal, bool tail)
 {
     const int  tv      = trace_variant();
-    const bool no_cull = literal || (!getenv("RTX_TRACE_VARIANT") && !sc->cull_useful);
+    const bool no_cull = literal || (!trace_variant_forced() && !sc->cull_useful);
     TraceKernel k;
     k.variant = !no_cull ? tv : tv == 3 ? 2 : tv == 4 ? 5 : tv;
     const int variant = k.variant;
@@ -2422,7 +2499,7 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     // grab size: 160 rays on the big coherent queues (fewer atomics, neighbouring rays stay on one wave), one wave's worth
     // on the smaller ones, where balance at the end of the launch is worth more (sweep: tools/dbg, RTX_TRACE_CHUNK)
     uint64_t chunk = n >= (64ull << 20) ? 160 : 64;
-    if (const char* e = getenv("RTX_TRACE_CHUNK")) chunk = std::max(16, atoi(e)); // experiments
+    if (knob(K_TRACE_CHUNK) > 0) chunk = (uint64_t)std::max(16ll, knob(K_TRACE_CHUNK)); // experiments
     unsigned nb    = (unsigned)std::min<uint64_t>(resident, (n + bs - 1) / bs);
     TailArgs ta;
     memset(&ta, 0, sizeof ta);
@@ -2653,12 +2730,9 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     int       rc   = check_params(p, &g, &rows);
     if (rc != RTX_OK) return rc;
     HIPCHECK(hipSetDevice(sc->device));
-    {
-        const char* e = getenv("RTX_JUMP_TABLE"); // 0: the literal 128-step jump in raygen (the tests compare the two)
-        if (!e || atoi(e) != 0) {
-            g.jump_tab = sc->d_jump_tab;
-            host_jump(0, p->seed_hi, g.jump_b);
-        }
+    if (knob(K_JUMP_TABLE) != 0) { // 0: the literal 128-step jump in raygen (the tests compare the two)
+        g.jump_tab = sc->d_jump_tab;
+        host_jump(0, p->seed_hi, g.jump_b);
     }
     hipStream_t st = (hipStream_t)stream;
     rtx_stats   local;
@@ -2677,8 +2751,7 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     // so the frame is the same, bit for bit (tests).  It paid 4-8 % on a rank's share of a frame split over 2-8 GPUs
     // while a launch ended with some waves a whole 1024-ray grab behind the others; with 128-ray grabs what is left
     // of a launch's end is its longest ray, which overlap cannot shorten, and one lane is as fast (tools/dbg/bands.py).
-    const char* ov_env  = getenv("RTX_OVERLAP"); // read per call: the tests switch it
-    const int   overlap = ov_env ? atoi(ov_env) : -1;
+    const int   overlap = (int)knob(K_OVERLAP);
     int lanes = overlap >= 1 ? std::min(overlap + 1, RTX_MAX_LANES) : 1; // off unless asked for: see above
     if ((uint32_t)lanes > rows) lanes = (int)rows;
     // slab sizing: whole pixels, at most `budget` paths in flight
@@ -2694,17 +2767,12 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     const uint64_t lane_bytes = (2 * qbytes + cap * 16 + cap * 12 + cap * 8 + bin_bytes + 255) & ~255ull;
     char*          ws         = nullptr;
     if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
-    // bin the queues that feed depth >= sort_depth (RTX_SORT_DEPTH; 0 = never).  Read per call: the tests switch it.
-    const char* sd_env     = getenv("RTX_SORT_DEPTH");
-    const int   sort_depth = sd_env ? atoi(sd_env) : 2;
+    // bin the queues that feed depth >= sort_depth (knob SORT_DEPTH; 0 = never)
+    const int   sort_depth = (int)knob(K_SORT_DEPTH);
     // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~2.5 M rays the closest-hit
     // pass it speeds up is too short to pay that back (tools/dbg/bands.py: a rank's share under an 8-way split)
-    const char*     sm_env  = getenv("RTX_SORT_MIN");
-    const long long bin_min = sm_env ? atoll(sm_env) : 2500000ll; // (4 M before the scatter got cheaper)
-    static const int sort_every = [] { // experiments: bin every k-th eligible depth (RTX_SORT_EVERY; huge = once)
-        const char* e = getenv("RTX_SORT_EVERY");
-        return e ? std::max(1, atoi(e)) : 1;
-    }();
+    const long long bin_min    = knob(K_SORT_MIN); // (4 M before the scatter got cheaper)
+    const int       sort_every = (int)std::max(1ll, knob(K_SORT_EVERY)); // experiments: bin every k-th eligible depth (huge = once)
     if (!sc->h_alive) HIPCHECK(hipHostMalloc((void**)&sc->h_alive, RTX_MAX_LANES * sizeof(unsigned long long)));
     if (lanes > 1 && !sc->ev_fork) HIPCHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
     for (int l = 1; l < lanes; l++) {
@@ -2719,20 +2787,16 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     // chip, a pass per depth costs more in ramps and drains than in work.  RTX_TAIL_MAX = longest queue handed to it
     // (0: never); read per call, the tests switch it.  Same paths, same results: a path's RNG state and result slot are its own.
     unsigned long long* d_tail = (unsigned long long*)&sc->d_counters[RTX_MAX_LANES * 80];
-    const char*         tm_env   = getenv("RTX_TAIL_MAX");
-    const long long     tail_max = (count || !tail_capable(sc, literal)) ? 0 : tm_env ? atoll(tm_env) : TAIL_MAX_DEFAULT;
-    const char*         ts_env   = getenv("RTX_TAIL_SHADE_MIN");
-    const uint32_t      tail_shade_min = (uint32_t)std::min(64, std::max(1, ts_env ? atoi(ts_env) : 16));
+    const long long     tail_max = (count || !tail_capable(sc, literal)) ? 0 : knob(K_TAIL_MAX);
+    const uint32_t      tail_shade_min = (uint32_t)std::min(64ll, std::max(1ll, knob(K_TAIL_SHADE_MIN)));
     bool                tail_used = false;
     // RTX_RAYGEN_LEAN=0: k_raygen stores whole path records and the first shade pass reads them (the tests compare the two)
-    const char*         lr_env      = getenv("RTX_RAYGEN_LEAN");
-    const bool          lean_raygen = !lr_env || atoi(lr_env) != 0;
+    const bool          lean_raygen = knob(K_RAYGEN_LEAN) != 0;
     HIPCHECK(hipMemsetAsync(d_tail, 0, (TAIL_COUNTERS + EARLY_COUNTERS) * sizeof(uint64_t), st));
     // rays that miss the box of the whole tree and every unbounded object are answered by the shade pass that creates
     // them (see k_shade); not under the literal walk, which is there to walk, nor when asked not to (the tests compare)
     unsigned long long* d_early   = d_tail + TAIL_COUNTERS;
-    const char*         em_env    = getenv("RTX_EARLY_MISS");
-    const bool          early_miss = !literal && (!em_env || atoi(em_env) != 0);
+    const bool          early_miss = !literal && knob(K_EARLY_MISS) != 0;
 
     int        nev = 0;
     hipEvent_t evA, evB;
@@ -2834,7 +2898,7 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
             a.gs.tile = a.gs.tile_h = PATH_TILE, a.gs.slab_rows = (uint32_t)(a.npx / g.width);
             // a rank's rows under the band split are bands from all over the image: a tile as high as a band (and as
             // much wider) stays one compact region instead of a stack of strips band_world bands apart
-            static const bool band_tiles = !getenv("RTX_BAND_TILES") || atoi(getenv("RTX_BAND_TILES")) != 0;
+            const bool band_tiles = knob(K_BAND_TILES) != 0;
             if (band_tiles && g.band_rows && g.band_rows < PATH_TILE && a.px0 == 0 && a.gs.slab_rows % g.band_rows == 0)
                 a.gs.tile_h = g.band_rows, a.gs.tile = std::max<uint32_t>(PATH_TILE, PATH_TILE * PATH_TILE / g.band_rows);
         }

@@ -19,7 +19,7 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex", "rtx_tune_set", "rtx_tune_get", "rtx_tune_reset"]
 RTX_SCENE_F32_TEXTURES = 1
 RTX_NOALLOC_MAX_RAYS = 1 << 18
 
@@ -63,6 +63,9 @@ def lib() -> C.CDLL:
     sig("rtx_device_count", C.c_int, C.POINTER(C.c_int))
     sig("rtx_scene_create", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.POINTER(vp))
     sig("rtx_scene_create_ex", C.c_int, C.POINTER(rtx_scene_desc), C.c_int, C.c_uint32, C.POINTER(vp))
+    sig("rtx_tune_set", C.c_int, C.c_char_p, C.c_longlong)
+    sig("rtx_tune_get", C.c_int, C.c_char_p, C.POINTER(C.c_longlong))
+    sig("rtx_tune_reset", None)
     sig("rtx_scene_destroy", C.c_int, vp)
     sig("rtx_scene_device_bytes", C.c_int, vp, C.POINTER(C.c_uint64))
     sig("rtx_cull_data_build", C.c_int, C.POINTER(rtx_scene_desc), C.POINTER(C.c_uint16), f32p)
@@ -88,6 +91,19 @@ def lib() -> C.CDLL:
     sig("rtx_kd_free", None, C.POINTER(rtx_kd_tree))
     _lib = L
     return L
+
+
+def tune(**knobs):
+    """rtx_tune_reset, then rtx_tune_set for every NAME=value given (names as in include/rtx.h, any case)."""
+    lib().rtx_tune_reset()
+    for k, v in knobs.items():
+        _check(lib().rtx_tune_set(k.upper().encode(), int(v)))
+
+
+def tune_get(name: str) -> int:
+    v = C.c_longlong(0)
+    _check(lib().rtx_tune_get(name.upper().encode(), C.byref(v)))
+    return v.value
 
 
 def last_error() -> str:

@@ -19,6 +19,17 @@ from raytracer_amd import hip
 from util import GOLDEN, golden, psnr, same_bits, same_values, ulp_diff
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def tune():
+    """Switch the library's tuning knobs for one test (rtx_tune_set; reset to the defaults before every change and after
+    the test).  Keys as the old environment names: tune({"RTX_TAIL_MAX": "0"}) or tune(TAIL_MAX=0)."""
+    def set_(env=None, **kw):
+        knobs = {k[4:] if k.startswith("RTX_") else k: int(v) for k, v in dict(env or {}, **kw).items()}
+        hip.tune(**knobs)
+    yield set_
+    hip.tune()
 SCENES = ["teapot", "bunny", "pear", "materials", "dragon1"]
 ULP_TOL = 2
 
@@ -369,7 +380,7 @@ def test_full_size_frame_properties(built_scenes, device_scenes):
 
 
 @pytest.mark.gpu
-def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, monkeypatch):
+def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, tune):
     """rtx_render_device cuts small jobs into two halves that run on two streams (a pass of one hides the tail of
     the other).  The halves are independent slabs: same frame bit for bit, same ray counts, with either setting
     and also when the halves are cut further into slabs."""
@@ -377,7 +388,7 @@ def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, mon
     p = hip.make_params(192, 108, 8, 8, seed=(1, 2))
     frames = []
     for ov, mpf in (("0", 0), ("1", 0), ("1", 20000), ("0", 20000)):
-        monkeypatch.setenv("RTX_OVERLAP", ov)
+        tune(OVERLAP=ov)
         p.max_paths_in_flight = mpf
         bgr, acc, st = ds.render(sc.rtx_camera(), p)
         frames.append((bgr, acc, st))
@@ -388,33 +399,30 @@ def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, mon
 
 
 @pytest.mark.gpu
-def test_table_driven_seed_jump_equals_the_128_steps(built_scenes, device_scenes, monkeypatch):
+def test_table_driven_seed_jump_equals_the_128_steps(built_scenes, device_scenes, tune):
     """raygen seeds each path with Random_Seed (random.c:78-85); its 128-step jump is linear over GF(2), so the kernel
     looks it up (8 table entries XORed).  Same frame, bit for bit, as with the literal jump — for odd seeds too."""
     sc, ds = built_scenes("teapot"), device_scenes("teapot")
     for seed in ((1, 2), (0xFFFFFFFFFFFFFFFF, 0x8000000000000001), (0x0123456789ABCDEF, 0)):
         frames = []
         for tab in ("1", "0"):
-            monkeypatch.setenv("RTX_JUMP_TABLE", tab)
+            tune(JUMP_TABLE=tab)
             frames.append(ds.render(sc.rtx_camera(), hip.make_params(160, 90, 4, 3, seed=seed)))
         assert np.array_equal(frames[0][0], frames[1][0]) and same_bits(frames[0][1], frames[1][1])
         assert frames[0][2]["rays_at_depth"] == frames[1][2]["rays_at_depth"]
 
 
 @pytest.mark.gpu
-def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monkeypatch):
+def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, tune):
     """Between bounce passes the surviving rays are counting-sorted by origin cell and direction octant (big queues
     only by default).  Queue order does not enter any result: frames with binning forced on for every queue, off,
     and at the default threshold are the same bits; forced on, it really ran."""
     sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
     p = hip.make_params(480, 270, 8, 8, seed=(7, 8))
     frames = {}
-    monkeypatch.setenv("RTX_TAIL_MAX", "0")  # a pass per depth: the tail kernel would take these short queues before they are binned
+    # (TAIL_MAX = 0, a pass per depth: the tail kernel would take these short queues before they are binned)
     for name, env in (("forced", {"RTX_SORT_MIN": "1"}), ("off", {"RTX_SORT_DEPTH": "0"}), ("default", {})):
-        for k in ("RTX_SORT_MIN", "RTX_SORT_DEPTH"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        tune(env, TAIL_MAX=0)
         frames[name] = ds.render(sc.rtx_camera(), p)
     for name in ("off", "default"):
         assert same_bits(frames[name][1], frames["forced"][1]) and frames[name][2]["rays_at_depth"] == frames["forced"][2]["rays_at_depth"]
@@ -423,7 +431,7 @@ def test_ray_binning_only_reorders_the_queues(built_scenes, device_scenes, monke
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,w,h,spp,depth", [("materials", 320, 180, 8, 8), ("dragon1", 240, 135, 8, 8), ("pear", 160, 90, 4, 16), ("teapot", 200, 100, 4, 2)])
-def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeypatch, scene, w, h, spp, depth):
+def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, tune, scene, w, h, spp, depth):
     """Short queues go through the rest of the bounce loop in one launch (closest hit, shading and the next ray in
     the same lane: k_trace_flat<..., TAIL>) instead of a pass per depth.  The same paths with the same RNG streams:
     the frame, the rays per depth and the number of shaded hits are those of the per-depth passes, bit for bit,
@@ -433,10 +441,7 @@ def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeyp
     out = {}
     for name, env in (("passes", {"RTX_TAIL_MAX": "0"}), ("default", {}), ("late", {"RTX_TAIL_MAX": str(w * h * spp // 3)}),
                       ("one_lane", {"RTX_TAIL_SHADE_MIN": "1"}), ("full_wave", {"RTX_TAIL_SHADE_MIN": "64"}), ("literal", {})):
-        for k in ("RTX_TAIL_MAX", "RTX_TAIL_SHADE_MIN"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        tune(env)
         out[name] = ds.render(sc.rtx_camera(), hip.make_params(w, h, spp, depth, seed=(3, 5), flags=hip.RTX_TRACE_LITERAL) if name == "literal" else p)
     ref = out["passes"]
     assert sum(ref[2]["rays_at_depth"][2:]) > 0 or depth <= 2
@@ -450,7 +455,7 @@ def test_tail_kernel_renders_the_same_frame(built_scenes, device_scenes, monkeyp
 
 
 @pytest.mark.gpu
-def test_first_shade_pass_rebuilds_what_raygen_does_not_store(built_scenes, device_scenes, monkeypatch):
+def test_first_shade_pass_rebuilds_what_raygen_does_not_store(built_scenes, device_scenes, tune):
     """k_raygen stores only origin and direction; the first shade pass rebuilds throughput (1), path id and the RNG
     state camera_sample leaves behind (seed jump + jitter + lens draws).  Same frame as with whole records
     (RTX_RAYGEN_LEAN=0), bit for bit — jittered and pixel-centre rays, bands, sample ranges, slabs, both seed-jump forms."""
@@ -459,17 +464,16 @@ def test_first_shade_pass_rebuilds_what_raygen_does_not_store(built_scenes, devi
     cases = [dict(), dict(flags=hip.RTX_RENDER_PIXEL_CENTRES), dict(band=(8, 1, 3)), dict(sample_range=(2, 5)), dict(max_paths_in_flight=3000)]
     for kw in cases:
         for jt in ("1", "0"):
-            monkeypatch.setenv("RTX_JUMP_TABLE", jt)
             out = []
             for lean in ("0", "1"):
-                monkeypatch.setenv("RTX_RAYGEN_LEAN", lean)
+                tune(JUMP_TABLE=jt, RAYGEN_LEAN=lean)
                 out.append(ds.render(cam, hip.make_params(97, 61, 6, 5, seed=(11, 12), **kw)))
             assert np.array_equal(out[0][0], out[1][0]) and same_bits(out[0][1], out[1][1]), (kw, jt)
             assert out[0][2]["rays_at_depth"] == out[1][2]["rays_at_depth"] and out[0][2]["hits_shaded"] == out[1][2]["hits_shaded"]
 
 
 @pytest.mark.gpu
-def test_fast_index_divisions_decode_the_same_pixels(built_scenes, device_scenes, monkeypatch):
+def test_fast_index_divisions_decode_the_same_pixels(built_scenes, device_scenes, tune):
     """Path and pixel indices are decoded with multiply-shift divisions by the launch's fixed divisors (samples,
     width, tile sizes, band height).  Same frames as with the plain divisions (RTX_FAST_DIV=0), bit for bit, on sizes
     with ragged tiles, bands with a partial last band, sample ranges, slabs that cut the frame, one-sample and
@@ -481,14 +485,14 @@ def test_fast_index_divisions_decode_the_same_pixels(built_scenes, device_scenes
     for w, h, spp, depth, kw in cases:
         out = []
         for fd in ("0", "1"):
-            monkeypatch.setenv("RTX_FAST_DIV", fd)
+            tune(FAST_DIV=fd)
             out.append(ds.render(cam, hip.make_params(w, h, spp, depth, seed=(21, 22), **kw)))
         assert np.array_equal(out[0][0], out[1][0]) and same_bits(out[0][1], out[1][1]), (w, h, spp, kw)
         assert out[0][2]["rays_at_depth"] == out[1][2]["rays_at_depth"]
 
 
 @pytest.mark.gpu
-def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monkeypatch):
+def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, tune):
     """Frames whose sizes fit no tile, wave or slab boundary: one launch, tiny slabs, several lanes and a forced
     binning pass all give the same bits and trace the same rays."""
     sc, ds = built_scenes("materials"), device_scenes("materials")
@@ -497,10 +501,7 @@ def test_odd_frame_shapes_and_partitions_agree(built_scenes, device_scenes, monk
         for env, mpf in (({"RTX_TAIL_MAX": "0"}, 0), ({}, 0), ({}, 777), ({"RTX_TAIL_MAX": "0"}, 777), ({"RTX_OVERLAP": "3"}, 0),
                          ({"RTX_OVERLAP": "2", "RTX_SORT_MIN": "1", "RTX_TAIL_MAX": "0"}, 1500), ({"RTX_SORT_MIN": "1", "RTX_TAIL_MAX": "0"}, 0),
                          ({"RTX_OVERLAP": "1", "RTX_TAIL_MAX": "300", "RTX_TAIL_SHADE_MIN": "3"}, 1500)):
-            for k in ("RTX_OVERLAP", "RTX_SORT_MIN", "RTX_TAIL_MAX", "RTX_TAIL_SHADE_MIN"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+            tune(env)
             bgr, acc, st = ds.render(sc.rtx_camera(), hip.make_params(w, h, spp, depth, seed=(9, w), max_paths_in_flight=mpf))
             if base is None:
                 base = (bgr, acc, st)
@@ -556,7 +557,7 @@ def test_awkward_rays_match_the_oracle(built_scenes, device_scenes, scene):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,w,h,spp,depth", [("dragon1", 240, 135, 8, 8), ("materials", 320, 180, 8, 6), ("teapot", 200, 100, 4, 3), ("pear", 160, 90, 4, 5)])
-def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_scenes, monkeypatch, scene, w, h, spp, depth):
+def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_scenes, tune, scene, w, h, spp, depth):
     """A bounce ray that misses the box of the whole kd-tree and every unbounded object is answered (sky) by the shade
     pass that creates it instead of going through the queue, the closest-hit kernel and the next shade pass.  Frame,
     rays per depth (such a ray still counts: it is one Scene_ClosestHit answered) and shaded hits are those of the
@@ -565,10 +566,7 @@ def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_sce
     p = hip.make_params(w, h, spp, depth, seed=(13, 14))
     out = {}
     for name, env in (("traced", {"RTX_EARLY_MISS": "0"}), ("early", {}), ("early_passes", {"RTX_TAIL_MAX": "0"}), ("traced_passes", {"RTX_EARLY_MISS": "0", "RTX_TAIL_MAX": "0"})):
-        for k in ("RTX_EARLY_MISS", "RTX_TAIL_MAX"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        tune(env)
         out[name] = ds.render(sc.rtx_camera(), p)
     ref = out["traced"]
     for name, (bgr, acc, st) in out.items():

@@ -14,7 +14,7 @@ sc = scenes.build(scene)
 ds = hip.DeviceScene(sc.desc, 0)
 cam = sc.rtx_camera()
 acc = torch.zeros(H, W, 3, device="cuda:0")
-os.environ["RTX_TAIL_MAX"] = "0"
+hip.tune(TAIL_MAX=0)  # a pass per depth
 prev, rows = None, []
 timed = ds.render_device(cam, hip.make_params(W, H, SPP, D), acc.data_ptr())
 timed = ds.render_device(cam, hip.make_params(W, H, SPP, D), acc.data_ptr())
