@@ -1457,6 +1457,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     int      state     = ST_IDLE;
 
     f3       o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), odd = mk3(0, 0, 0);
+    u3       rot = {0, 0, 0}; // CULL: 16 on the axes where the direction is negative (box_missed2)
     uint32_t ridx = 0; // < 2^32: launch_trace checks
     uint32_t node = 0;
     float    tMax = RTX_INF;
@@ -1565,6 +1566,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                         cullOK         = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f; // false for any NaN / inf component
                     }
                     asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                    if (CULL) {
+                        rot = box_rotations(inv);
+                        asm volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z));
+                    }
                     // Scene_ClosestHitInArray (scene.c:73-98) does not depend on the tree walk: done here, where at
                     // least refill_min lanes share the instructions, instead of in FIN where one or two lanes do
                     pBest = RTX_INF;
@@ -1694,7 +1699,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     // both children's boxes against the segments they would be walked with; a child the ray cannot
                     // reach is neither fetched nor pushed
                     bool miss[2];
-                    box_missed2(S, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, o, inv, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
+                    box_missed2(S, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, o, inv, rot, goRight ? f2v{tMax, tNear} : f2v{tNear, tMax}, miss);
                     // (xor / and of lane masks are scalar instructions; `goRight ? miss[1] : miss[0]` made the compiler turn
                     // both flags into 0/1 registers and select those: 8 vector instructions per step)
                     const bool differ = miss[0] != miss[1], swap = goRight && differ;
@@ -1905,6 +1910,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     cullOK         = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
                 }
                 asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z), "+v"(odd.x), "+v"(odd.y), "+v"(odd.z));
+                if (CULL) {
+                    rot = box_rotations(inv);
+                    asm volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z));
+                }
                 pBest = RTX_INF;
                 pRef  = HIT_MISS;
                 for (uint32_t i = 0; i < S.n_planes; i++) {

@@ -352,24 +352,35 @@ DEV bool box_missed(const SceneDev& S, uint32_t wx, uint32_t wy, uint32_t wz, f3
     return wx != 0x0000FFFFu && tn > tf;
 }
 
-DEV void box_missed2(const SceneDev& S, uint32_t lx, uint32_t ly, uint32_t lz, uint32_t rx, uint32_t ry, uint32_t rz, f3 o, f3 inv, f2v tMax,
+// (The walk's form: `rot` = 16 on an axis where the direction is negative, else 0.  Rotating a word by it puts the plane the
+// ray meets first into the low half and the other into the high half — with min <= max on the grid and a monotone
+// decode that IS min / max of the two ray parameters, so the twelve v_min / v_max of the slab test become six rotations
+// and the outcome is the one box_missed computes.)
+struct u3 {
+    uint32_t x, y, z;
+};
+DEV void box_missed2(const SceneDev& S, uint32_t lx, uint32_t ly, uint32_t lz, uint32_t rx, uint32_t ry, uint32_t rz, f3 o, f3 inv, u3 rot, f2v tMax,
                      bool miss[2])
 {
     const f2v sx = f2v{S.cull_scale[0], S.cull_scale[0]}, sy = f2v{S.cull_scale[1], S.cull_scale[1]}, sz = f2v{S.cull_scale[2], S.cull_scale[2]};
     const float nx1 = -(o.x - S.cull_lo[0]), ny1 = -(o.y - S.cull_lo[1]), nz1 = -(o.z - S.cull_lo[2]);
     const f2v nx = f2v{nx1, nx1}, ny = f2v{ny1, ny1}, nz = f2v{nz1, nz1};
     const f2v ix = f2v{inv.x, inv.x}, iy = f2v{inv.y, inv.y}, iz = f2v{inv.z, inv.z};
-    const f2v t1x = __builtin_elementwise_fma(f2v{BOX_LO(lx), BOX_LO(rx)}, sx, nx) * ix, t2x = __builtin_elementwise_fma(f2v{BOX_HI(lx), BOX_HI(rx)}, sx, nx) * ix;
-    const f2v t1y = __builtin_elementwise_fma(f2v{BOX_LO(ly), BOX_LO(ry)}, sy, ny) * iy, t2y = __builtin_elementwise_fma(f2v{BOX_HI(ly), BOX_HI(ry)}, sy, ny) * iy;
-    const f2v t1z = __builtin_elementwise_fma(f2v{BOX_LO(lz), BOX_LO(rz)}, sz, nz) * iz, t2z = __builtin_elementwise_fma(f2v{BOX_HI(lz), BOX_HI(rz)}, sz, nz) * iz;
+    const uint32_t Lx = __builtin_amdgcn_alignbit(lx, lx, rot.x), Rx = __builtin_amdgcn_alignbit(rx, rx, rot.x);
+    const uint32_t Ly = __builtin_amdgcn_alignbit(ly, ly, rot.y), Ry = __builtin_amdgcn_alignbit(ry, ry, rot.y);
+    const uint32_t Lz = __builtin_amdgcn_alignbit(lz, lz, rot.z), Rz = __builtin_amdgcn_alignbit(rz, rz, rot.z);
+    const f2v t1x = __builtin_elementwise_fma(f2v{BOX_LO(Lx), BOX_LO(Rx)}, sx, nx) * ix, t2x = __builtin_elementwise_fma(f2v{BOX_HI(Lx), BOX_HI(Rx)}, sx, nx) * ix;
+    const f2v t1y = __builtin_elementwise_fma(f2v{BOX_LO(Ly), BOX_LO(Ry)}, sy, ny) * iy, t2y = __builtin_elementwise_fma(f2v{BOX_HI(Ly), BOX_HI(Ry)}, sy, ny) * iy;
+    const f2v t1z = __builtin_elementwise_fma(f2v{BOX_LO(Lz), BOX_LO(Rz)}, sz, nz) * iz, t2z = __builtin_elementwise_fma(f2v{BOX_HI(Lz), BOX_HI(Rz)}, sz, nz) * iz;
     const f2v tk  = tMax * f2v{S.cull_kt, S.cull_kt};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const float tn = fmaxf(fmaxf(fminf(t1x[k], t2x[k]), fminf(t1y[k], t2y[k])), fmaxf(fminf(t1z[k], t2z[k]), 0.0f));
-        const float tf = fminf(fminf(fmaxf(t1x[k], t2x[k]), fmaxf(t1y[k], t2y[k])), fminf(fmaxf(t1z[k], t2z[k]), tk[k]));
+        const float tn = fmaxf(fmaxf(t1x[k], t1y[k]), fmaxf(t1z[k], 0.0f));
+        const float tf = fminf(fminf(t2x[k], t2y[k]), fminf(t2z[k], tk[k]));
         miss[k]        = (k == 0 ? lx : rx) != 0x0000FFFFu && tn > tf;
     }
 }
+DEV u3 box_rotations(f3 inv) { return u3{(__float_as_uint(inv.x) >> 27) & 16u, (__float_as_uint(inv.y) >> 27) & 16u, (__float_as_uint(inv.z) >> 27) & 16u}; }
 
 DEV bool Sphere_HitAt(float4 sp, f3 o, f3 d, float tMin, float tMax, float& t) // :55
 {
