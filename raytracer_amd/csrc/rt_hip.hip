@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...)
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
 enum { K_OVERLAP, K_SORT_DEPTH, K_SORT_MIN, K_SORT_EVERY, K_TAIL_MAX, K_TAIL_SHADE_MIN, K_JUMP_TABLE, K_RAYGEN_LEAN, K_EARLY_MISS, K_FAST_DIV,
-       K_BAND_TILES, K_TRACE_CHUNK, K_COUNT };
+       K_BAND_TILES, K_TRACE_CHUNK, K_AHEAD, K_COUNT };
 struct Knob {
     const char* name;
     long long   dflt, value;
@@ -89,6 +89,7 @@ static Knob g_knobs[K_COUNT] = {
     {"FAST_DIV", 1, 0},           // 0: plain divisions in the index decode
     {"BAND_TILES", 1, 0},         // 0: 32 x 32 path tiles under the band split too
     {"TRACE_CHUNK", 0, 0},        // rays per work grab of the closest-hit kernel; 0 = by queue length
+    {"AHEAD", 1, 0},              // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
 };
 static std::once_flag g_knobs_once;
 static void knobs_init()
@@ -1179,6 +1180,7 @@ struct TailArgs {
     uint32_t            max_depth;
     unsigned long long* counts;   // [d]: rays traced at depth d beyond depth0's own; [RTX_MAX_DEPTH]: paths shaded
     uint32_t            shade_min; // lanes that must wait before the shade block runs
+    const unsigned long long* n_dev; // not null: the queue's length is read here (the pass was launched before the host knew it; `n` is an upper bound)
 };
 
 template <bool COUNT>
@@ -1437,10 +1439,18 @@ DEV uint32_t lane_read(uint32_t v, uint32_t src) { return (uint32_t)__builtin_am
 template <bool COUNT, bool CULL, bool COOP, bool TAIL = false>
 // (waves_per_eu(6): the walk needs 88 VGPRs as the compiler likes it, 5 waves per SIMD; held to 80 it spills two
 // values that only the refill touches and runs 6 waves per SIMD — 95.0 -> 91.8 ms; 7 waves cost 8 spills and lose)
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? TAIL_WAVES : 6))) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? TAIL_WAVES : 6))) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n_bound,
                                                     uint32_t* __restrict__ hits, uint64_t hstride, unsigned long long* work,
-                                                    uint32_t chunk, uint64_t* counters, uint32_t tune, TailArgs ta)
+                                                    uint32_t chunk_host, uint64_t* counters, uint32_t tune, TailArgs ta)
 {
+    // The queue's length: the launch argument, or — for a pass the host queued behind the shade pass that fills the queue,
+    // without waiting for its count — what that shade pass left on the device (wave-uniform scalar loads)
+    uint64_t n     = n_bound;
+    uint32_t chunk = chunk_host;
+    if (ta.n_dev) {
+        n = *ta.n_dev;
+        if ((tune >> 26) & 1u) chunk = n >= (64ull << 20) ? 160u : 64u; // launch_trace's choice, made here
+    }
     // Block scheduling (wave-uniform): the INNER and LEAF blocks cost ~60 and ~90 vector instructions whatever
     // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
     // enough lanes wait for it (or nothing else can run); lanes in the other state simply keep their place.
@@ -2202,16 +2212,19 @@ __global__ __launch_bounds__(BIN_CHUNKS) void k_bin_scan_chunks(uint32_t* __rest
     chunk[tid] = before + inc - c;
 }
 
-__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk,
-                                                     const uint2* __restrict__ keys, Queue qout)
+__global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, const unsigned long long* n_dev, const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ chunk, const uint2* __restrict__ keys, Queue qout)
 {
+    if (n_dev) n = *n_dev; // launched before the host knew the queue's length: `n` was an upper bound for the grid
     // Each lane gathers its own path's 14 dwords (coalesced: the source is SoA); the records then go through LDS so
     // that FOUR lanes store the four 16-byte quarters of ONE record in the same instruction — a store instruction
     // covers 16 whole 64-byte lines instead of a quarter of 64 different ones.
     __shared__ uint4    s_rec[256 * 4 + 256 / 16]; // [thread][quarter], one uint4 of padding per 16 threads
     __shared__ uint64_t s_pos[256];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63u;
-    const uint64_t i   = (uint64_t)blockIdx.x * blockDim.x + tid;
+    // (tiles of 256 paths, block-uniform loop: a grid sized for an upper bound of n costs nothing when n turns out small)
+    for (uint64_t tile = blockIdx.x; tile * 256 < n; tile += gridDim.x) {
+    const uint64_t i   = tile * 256 + tid;
     uint64_t       pos = ~0ull;
     if (i < n) {
         const uint2 ks = keys[i]; // bin, slot inside the bin
@@ -2231,6 +2244,8 @@ __global__ __launch_bounds__(256) void k_bin_scatter(Queue qin, uint64_t n, cons
         const uint32_t r = wbase + 16u * k + (lane >> 2), q = lane & 3u; // record (thread that gathered it), quarter
         const uint64_t pr = s_pos[r];
         if (pr != ~0ull) ((uint4*)((uint32_t*)qout.base + pr * Q_RECORD))[q] = s_rec[r * 4 + (r >> 4) + q];
+    }
+    __syncthreads();
     }
 }
 
@@ -2474,8 +2489,9 @@ static int resident_blocks(rtx_scene* sc, const TraceKernel& k, unsigned* out)
 
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
                         bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false,
-                        const TailArgs* tail = nullptr)
+                        const TailArgs* tail = nullptr, const unsigned long long* n_dev = nullptr)
 {
+    // n_dev: the queue's length is still on the device; n is an upper bound (flat kernels only: render_device_impl checks)
     if (n == 0) return RTX_OK;
     if (n > 0xFFFFFF00ull) return fail(RTX_E_LIMIT, "too many rays for one launch");
     const TraceKernel tk      = pick_trace_kernel(sc, count, literal, tail != nullptr);
@@ -2513,8 +2529,10 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     TailArgs ta;
     memset(&ta, 0, sizeof ta);
     if (tail) ta = *tail;
+    if (n_dev && variant < 2) return fail(RTX_E_INVALID, "this closest-hit kernel takes the queue's length from the host");
+    ta.n_dev = n_dev;
     hipLaunchKernelGGL(tk.kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
-                       tune | (bounce_rays && !count ? 1u << 25 : 0u), ta);
+                       tune | (bounce_rays && !count ? 1u << 25 : 0u) | (n_dev && knob(K_TRACE_CHUNK) <= 0 ? 1u << 26 : 0u), ta);
     HIPCHECK(hipGetLastError());
     return RTX_OK;
 }
@@ -2850,7 +2868,14 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
         Queue               qin;
         uint32_t            depth;
         bool                active, bin, last;
+        bool                ahead;   // the next depth's binning and closest-hit pass are already queued (on the count the device holds)
+        hipEvent_t          ev_cnt;  // the survivors' count has reached the host
     } L[RTX_MAX_LANES];
+    // A depth's closest-hit pass does not wait for the host (knob AHEAD): the kernel is persistent — its grid does not depend
+    // on the queue's length — and reads that length from the counter the shade pass leaves on the device, so it is queued
+    // right behind that shade pass (and the binning pass, whose scatter reads the same counter).  The host reads the count
+    // while the closest-hit pass runs and sizes the NEXT shade pass with it; the device never idles through a round trip.
+    const bool ahead_ok = knob(K_AHEAD) != 0 && pick_trace_kernel(sc, count, literal, false).variant >= 2;
     for (int l = 0; l < lanes; l++) {
         char* w       = ws + l * lane_bytes;
         L[l].s        = l == 0 ? st : sc->aux_stream[l - 1];
@@ -2863,20 +2888,32 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
         L[l].work     = (unsigned long long*)&sc->d_counters[80 * l + 16];
         L[l].h_alive  = sc->h_alive + l;
         L[l].active   = false;
+        L[l].ahead    = false;
+        if ((rc = get_event(sc, nev++, &L[l].ev_cnt)) != RTX_OK) return rc;
     }
     auto soa = [&](const Lane& a, int b) { return Queue{a.qb[b], cap, 1}; };
     auto aos = [&](const Lane& a, int b) { return Queue{a.qb[b], 1, Q_RECORD}; };
 
+    auto launch_binning = [&](Lane& a, uint64_t n, const unsigned long long* n_dev, Queue from, Queue to) {
+        uint32_t* chunk = a.bin_cnt + (1u << BIN_BITS);
+        hipLaunchKernelGGL(k_bin_scan, dim3(BIN_CHUNKS), dim3(1024), 0, a.s, a.bin_cnt, chunk);
+        hipLaunchKernelGGL(k_bin_scan_chunks, dim3(1), dim3(BIN_CHUNKS), 0, a.s, chunk);
+        hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)std::min<uint64_t>(blocks_for(n, 256), 1u << 16)), dim3(256), 0, a.s, from, n, n_dev, a.bin_cnt, chunk,
+                           a.bin_keys, to);
+    };
     // one bounce pass of a lane: closest hit, shade + compaction, and the survivors' count on its way to the host
     auto enqueue_depth = [&](Lane& a) -> int {
         const uint32_t depth = a.depth;
         local.rays_at_depth[depth] += a.n;
         local.rays_total += a.n;
-        int lrc = RTX_OK;
-        int r   = timed(1, depth, a.s, [&] {
-            lrc = launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
-        });
-        if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
+        int lrc = RTX_OK, r = RTX_OK;
+        if (!a.ahead) { // (else: queued behind the previous depth's shade pass)
+            r = timed(1, depth, a.s, [&] {
+                lrc = launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
+            });
+            if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
+        }
+        a.ahead = false;
         local.trace_launches++;
         HIPCHECK(hipMemsetAsync(a.d_cnt, 0, sizeof(unsigned long long), a.s));
         a.last = depth + 1 == p->max_depth;
@@ -2890,6 +2927,21 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
         if (r != RTX_OK) return r;
         *a.h_alive = 0;
         if (!a.last) HIPCHECK(hipMemcpyAsync(a.h_alive, a.d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, a.s));
+        HIPCHECK(hipEventRecord(a.ev_cnt, a.s));
+        // (not when this queue could already have gone to the tail launch: then the next one may, and that is another kernel)
+        if (ahead_ok && !a.last && (long long)a.n > tail_max) {
+            Queue nq = soa(a, a.cur ^ 1);
+            if (a.bin) {
+                r = timed(4, depth + 1, a.s, [&] { launch_binning(a, a.n, a.d_cnt, nq, aos(a, a.cur)); });
+                if (r != RTX_OK) return r;
+                nq = aos(a, a.cur);
+            }
+            r = timed(1, depth + 1, a.s, [&] {
+                lrc = launch_trace(sc, nq.base, nq.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, true, nullptr, a.d_cnt);
+            });
+            if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
+            a.ahead = true;
+        }
         return RTX_OK;
     };
     uint64_t next_px = 0;
@@ -2918,6 +2970,17 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     };
     auto advance = [&](Lane& a) -> int { // the lane's pass has finished: bin and go one deeper, or close the slab
         a.n   = a.last ? 0 : *a.h_alive;
+        if (a.ahead) { // the queue has been binned (a.bin) and its closest-hit pass is running: on to that depth's shade pass
+            if (!a.bin) a.cur ^= 1;
+            a.qin = a.bin ? aos(a, a.cur) : soa(a, a.cur);
+            a.depth++;
+            if (a.n > 0) return enqueue_depth(a);
+            a.ahead = false; // (it found an empty queue)
+            int r = timed(3, 0, a.s, [&] {
+                hipLaunchKernelGGL(k_resolve_slab, dim3(blocks_for(a.npx, 256)), dim3(256), 0, a.s, a.result, cap, a.gs, a.px0, a.npx, d_accum);
+            });
+            return r != RTX_OK ? r : start_slab(a);
+        }
         a.cur ^= 1;
         a.qin = soa(a, a.cur);
         if (a.n > 0 && (long long)a.n <= tail_max && a.depth + 1 < p->max_depth) {
@@ -2937,13 +3000,7 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
             a.depth   = p->max_depth;
         }
         if (a.bin && a.n > 0) {
-            int r = timed(4, a.depth, a.s, [&] {
-                uint32_t* chunk = a.bin_cnt + (1u << BIN_BITS);
-                hipLaunchKernelGGL(k_bin_scan, dim3(BIN_CHUNKS), dim3(1024), 0, a.s, a.bin_cnt, chunk);
-                hipLaunchKernelGGL(k_bin_scan_chunks, dim3(1), dim3(BIN_CHUNKS), 0, a.s, chunk);
-                hipLaunchKernelGGL(k_bin_scatter, dim3(blocks_for(a.n, 256)), dim3(256), 0, a.s, a.qin, a.n, a.bin_cnt, chunk, a.bin_keys,
-                                   aos(a, a.cur ^ 1));
-            });
+            int r = timed(4, a.depth, a.s, [&] { launch_binning(a, a.n, nullptr, a.qin, aos(a, a.cur ^ 1)); });
             if (r != RTX_OK) return r;
             a.cur ^= 1;
             a.qin = aos(a, a.cur);
@@ -2966,7 +3023,7 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     while (any_active()) {
         for (int l = 0; l < lanes; l++) {
             if (!L[l].active) continue;
-            HIPCHECK(hipStreamSynchronize(L[l].s));
+            HIPCHECK(hipEventSynchronize(L[l].ev_cnt)); // the lane's shade pass is done and its count is here
             if ((rc = advance(L[l])) != RTX_OK) return rc;
         }
     }

@@ -577,6 +577,31 @@ def test_rays_answered_in_the_shade_pass_change_nothing(built_scenes, device_sce
         assert out["early"][2]["rays_early_miss"] > 0.1 * ref[2]["rays_total"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,depth", [("dragon1", 640, 360, 16, 8), ("materials", 320, 180, 8, 6), ("teapot", 200, 100, 4, 3), ("pear", 160, 90, 4, 5)])
+def test_passes_queued_ahead_of_the_host_change_nothing(built_scenes, device_scenes, tune, scene, w, h, spp, depth):
+    """a depth's binning and closest-hit pass are queued right behind the shade pass that fills their
+    queue and read its length from the device; the host reads the count while they run (knob AHEAD).  Frame, rays per
+    depth, shaded hits and launch counts are those of the loop that waits for every count (AHEAD=0): with binning on
+    (dragon1 at this size has queues above SORT_MIN) and off, with the tail launch, with two lanes, and under
+    COUNT_VISITS (another kernel instance)."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    cases = (({}, 0), ({"RTX_TAIL_MAX": "0"}, 0), ({"RTX_SORT_MIN": "1000"}, 0), ({"RTX_OVERLAP": "1"}, 0), ({}, hip.RTX_RENDER_COUNT_VISITS))
+    for env, flags in cases:
+        q = hip.make_params(w, h, spp, depth, seed=(21, 22), flags=flags)
+        tune(dict(env, RTX_AHEAD="0"))
+        ref = ds.render(sc.rtx_camera(), q)
+        tune(dict(env, RTX_AHEAD="1"))
+        got = ds.render(sc.rtx_camera(), q)
+        assert np.array_equal(got[0], ref[0]) and same_bits(got[1], ref[1]), env
+        for k in ("rays_at_depth", "rays_total", "hits_shaded", "visits_inner", "visits_leaf", "visits_prim"):
+            assert got[2][k] == ref[2][k], (env, k)
+        # (how many rays the shade passes answered depends on the depth at which the tail launch — which traces every
+        # ray — takes over, and a pass queued ahead puts that one depth later)
+        if env.get("RTX_TAIL_MAX") == "0":
+            assert got[2]["rays_early_miss"] == ref[2]["rays_early_miss"], env
+
+
 def test_compact_textures_are_lossless(built_scenes, device_scenes):
     """SURVEY §8f-3, compact texture formats.  A texture whose channels take at most 256 distinct values (every imported
     BMP: sRGBToLinear(byte / 255), texture.c:15-47) lives on the device as 3 bytes per texel + a palette of the original
