@@ -229,7 +229,9 @@ DEV f3 Random_InSphere(Rng& r, float radius) // random.c:140
     float phi = 2.0f * PI32 * e1;
     float ct  = e2;
     float st  = sqrtf(1.0f - ct * ct); // POWF(x,2): the pinned build folds powf(x,2) to x*x
-    return mk3(rho * st * cosf(phi), rho * st * sinf(phi), rho * ct);
+    float sp, cp;
+    sincosf(phi, &sp, &cp); // (one argument reduction for both)
+    return mk3(rho * st * cp, rho * st * sp, rho * ct);
 }
 
 DEV f3 Random_OnSphere(Rng& r, float radius) // random.c:159
@@ -240,7 +242,9 @@ DEV f3 Random_OnSphere(Rng& r, float radius) // random.c:159
     float phi = 2.0f * PI32 * e1;
     float ct  = e2;
     float st  = sqrtf(1.0f - ct * ct);
-    return mk3(rho * st * cosf(phi), rho * st * sinf(phi), rho * ct);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    return mk3(rho * st * cp, rho * st * sp, rho * ct);
 }
 
 DEV f3 Random_InHemisphere(Rng& r, f3 facing, float radius) // random.c:176 (radius applied twice)
@@ -677,7 +681,9 @@ DEV f3 CosWeightedHemisphere_Sample(Rng& rng, f3 n) // :274
     float st = sqrtf(1.0f - e0);
     float ct = sqrtf(e0);
     float phi = 2.0f * PI32 * e1;
-    f3    local = mk3(cosf(phi) * st, sinf(phi) * st, ct);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    f3    local = mk3(cp * st, sp * st, ct);
     return vec3_Reorient(local, vec3_OrthonormalBasis(n));
 }
 
@@ -721,8 +727,10 @@ DEV f3 GGXVNDF_Sample(f3 Ve, float ax, float ay, float U1, float U2) // :415
     f3    T2    = vcross(Vh, T1);
     float r     = sqrtf(U1);
     float phi   = 2.0f * PI32 * U2;
-    float t1    = r * cosf(phi);
-    float t2    = r * sinf(phi);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    float t1    = r * cp;
+    float t2    = r * sp;
     float s     = 0.5f * (1.0f + Vh.z);
     t2          = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     f3 Nh = vadd(vadd(vmuls(T1, t1), vmuls(T2, t2)), vmuls(Vh, sqrtf(maxf_(0.0f, 1.0f - t1 * t1 - t2 * t2))));
@@ -809,8 +817,8 @@ DEV bool Disney_Clearcoat_Bounce(const rtx_material& m, f3 din, const HitD& h, R
     float ce = sqrtf((1.0f - powf(a2, 1.0f - u0)) / (1.0f - a2));
     float az = 2.0f * PI32 * u1;
     float se = sqrtf(1.0f - ce * ce);
-    float ca = cosf(az);
-    float sa = sinf(az);
+    float sa, ca;
+    sincosf(az, &sa, &ca);
     f3    mn = mk3(se * ca, se * sa, ce);
     f3    w_out = vnorm(vec3_Reflect(vmuls(w_in, -1.0f), mn));
     // BRDF_Disney_Clearcoat :548
