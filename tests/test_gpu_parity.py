@@ -380,6 +380,28 @@ def test_full_size_frame_properties(built_scenes, device_scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,depth", [("bunny", 8), ("pear", 16)])
+def test_configs_2_and_4_at_full_size(built_scenes, device_scenes, scene, depth):
+    """BASELINE configs 2 (bunny, metal on a diffuse ground, 1080p, 64 spp, depth 8) and 4 (textured pear under a cube map,
+    depth 16) at their full size, through properties: the frame of the default (culled, cooperative) kernel equals the
+    frame of the literal walk bit for bit — so do the rays per depth and the shaded hits —, two band shares add up to it
+    exactly, and the primary pass traces one ray per camera path.  (Against the reference these configs are pinned at the
+    golden sizes: test_seeded_render_vs_reference.)"""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    cam = sc.rtx_camera()
+    W, H, spp = 1920, 1080, 64
+    _, a, sa = ds.render(cam, hip.make_params(W, H, spp, depth), want_bgr=False)
+    _, b, sb = ds.render(cam, hip.make_params(W, H, spp, depth, flags=hip.RTX_TRACE_LITERAL), want_bgr=False)
+    assert same_bits(a, b)
+    assert sa["rays_at_depth"] == sb["rays_at_depth"] and sa["hits_shaded"] == sb["hits_shaded"]
+    assert sa["rays_at_depth"][0] == W * H * spp and sa["rays_total"] == sum(sa["rays_at_depth"])
+    acc = np.zeros_like(a)
+    for r in range(2):
+        acc += ds.render(cam, hip.make_params(W, H, spp, depth, band=(8, r, 2)), want_bgr=False)[1]
+    assert same_bits(acc, a)
+
+
+@pytest.mark.gpu
 def test_two_lanes_render_the_same_frame_as_one(built_scenes, device_scenes, tune):
     """rtx_render_device cuts small jobs into two halves that run on two streams (a pass of one hides the tail of
     the other).  The halves are independent slabs: same frame bit for bit, same ray counts, with either setting
