@@ -1505,14 +1505,38 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     Visits   vis  = {0, 0, 0, 0};
     uint32_t ws[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // COUNT: iterations, INNER runs / lanes, LEAF runs / lanes, POP runs / lanes, FIN runs
 
-    // FIN: Scene_ClosestHit's merge with the unbounded list (scene.c:122-142) and the hit record
+    // FIN: Scene_ClosestHit's merge with the unbounded list (scene.c:73-98, 122-142) and the hit record.  The unbounded
+    // (plane) list does not depend on the walk; it is tested here, where the records of all the walks a wave has finished
+    // are written at once, instead of when a ray is loaded — its result would sit in two registers for the whole walk.
     auto write_hit = [&](uint32_t ref, float tH, float uH, float vH) {
         if (ref == HIT_MISS) tH = RTX_INF, uH = 0.0f, vH = 0.0f;
+        if (!TAIL) {
+            pBest = RTX_INF;
+            pRef  = HIT_MISS;
+            for (uint32_t i = 0; i < S.n_planes; i++) {
+                const float* pl = S.plane + 8ull * i;
+                float        tp2;
+                if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                    pBest = tp2;
+                    pRef  = HIT_PLANE | i;
+                }
+            }
+        }
         if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f;
         hits[0 * hstride + ridx] = ref;
         hits[1 * hstride + ridx] = __float_as_uint(tH);
         hits[2 * hstride + ridx] = __float_as_uint(uH);
         hits[3 * hstride + ridx] = __float_as_uint(vH);
+    };
+
+    // COOP: a walk's closest hit so far is {bestT (register), WWIN(lane) = {ref, u, v} (LDS, written by the lane that made
+    // the winning test)}; the three values come into registers only when the record is written
+    auto take_best = [&]() {
+        best = HIT_MISS, bu = 0.0f, bv = 0.0f;
+        if (bestT < RTX_INF) {
+            const uint4 w = WWIN(lane);
+            best = w.x, bu = __uint_as_float(w.y), bv = __uint_as_float(w.z);
+        }
     };
 
     for (;;) {
@@ -1522,6 +1546,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if ((exhausted && nidle == 64u) || (!exhausted && nidle >= refill_min)) {
             if (!TAIL && state == ST_DONE) {
+                if (COOP) take_best();
                 write_hit(best, bestT, bu, bv);
                 state = ST_IDLE;
             }
@@ -1580,11 +1605,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                         rot = box_rotations(inv);
                         asm volatile("" : "+v"(rot.x), "+v"(rot.y), "+v"(rot.z));
                     }
-                    // Scene_ClosestHitInArray (scene.c:73-98) does not depend on the tree walk: done here, where at
-                    // least refill_min lanes share the instructions, instead of in FIN where one or two lanes do
+                    // TAIL: Scene_ClosestHitInArray (scene.c:73-98) when the ray is loaded (the other kernels: in write_hit)
                     pBest = RTX_INF;
                     pRef  = HIT_MISS;
-                    for (uint32_t i = 0; i < S.n_planes; i++) {
+                    for (uint32_t i = 0; TAIL && i < S.n_planes; i++) {
                         const float* pl = S.plane + 8ull * i;
                         float        tp2;
                         if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
@@ -1747,7 +1771,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
             const uint32_t incl  = wave_scan_add(cnt), excl = incl - cnt;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             WOWN(lane) = 0u;
-            WKEY(lane) = ~0ull;
+            // a test takes an owner's slot only with a t strictly below the owner's closest so far (an earlier step's hit
+            // wins a tie: it is earlier in the list); among this step's tests the smaller (t, position) wins
+            WKEY(lane) = (unsigned long long)__float_as_uint(bestT) << 32;
             LDS_ORDER();
             if (cnt != 0u && excl < 64u) WOWN(excl) = excl << 6 | lane; // head of this owner's run of slots
             LDS_ORDER();
@@ -1778,7 +1804,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     hitS = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c), so, sd, RT_EPSILON, sT, tS, uS, vS);
                 }
                 if (hitS) {
-                    keyS = (unsigned long long)__float_as_uint(tS) << 32 | lane;
+                    keyS = (unsigned long long)__float_as_uint(tS) << 32 | (lane + 1u);
                     atomicMin(&WKEY(owner), keyS);
                 }
             }
@@ -1788,17 +1814,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
             if (cnt != 0u && excl < 64u) {
                 const uint32_t used = cnt < 64u - excl ? cnt : 64u - excl;
                 if (COUNT) vis.prim += used;
-                const unsigned long long kk = WKEY(lane);
-                if (kk != ~0ull) {
-                    const float tW = __uint_as_float((uint32_t)(kk >> 32));
-                    if (tW < bestT) { // strict: an earlier step's hit wins a tie (it is earlier in the list)
-                        const uint4 w = WWIN(lane);
-                        bestT = tW, best = w.x, bu = __uint_as_float(w.y), bv = __uint_as_float(w.z);
-                    }
-                }
+                bestT = __uint_as_float((uint32_t)(WKEY(lane) >> 32)); // (the winner's {ref, u, v} stay in WWIN(lane))
                 leafPos += used;
                 if (leafPos == leafEnd) {
-                    if (best != HIT_MISS) fin = true; // a leaf that reports a hit ends the walk
+                    if (bestT < RTX_INF) fin = true; // a leaf that reports a hit ends the walk
                     else pop = true;
                 }
             }
@@ -1859,12 +1878,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 tMax          = __uint_as_float(e.y);
                 state         = ST_INNER;
             } else { // tree exhausted
-                best = HIT_MISS;
-                fin  = true;
+                best  = HIT_MISS;
+                bestT = RTX_INF;
+                fin   = true;
             }
         }
         if (fin) {
             if (TAIL) { // Scene_ClosestHit's merge with the unbounded list (as in write_hit); the hit stays in the lane
+                if (COOP) take_best();
                 if (best == HIT_MISS) bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
                 if (pRef != HIT_MISS && (best == HIT_MISS || pBest < bestT)) best = pRef, bestT = pBest, bu = 0.0f, bv = 0.0f;
                 state = ST_SHADE;
