@@ -36,7 +36,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(LIB_DIR, "librt_hip.so")
+    path = os.environ.get("RTX_HIP_LIB") or os.path.join(LIB_DIR, "librt_hip.so")  # (RTX_HIP_LIB: another build of it, tools/ab2.sh)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension was not built (python -m raytracer_amd.build)")
     # ONE HIP runtime per process.  PyTorch's wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) and
