@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     for (;;) {
         // (a lane whose walk has finished keeps its hit — DONE — until the wave next refills or ends: the record's four
         // stores and the merge with the unbounded list then run for many lanes at once instead of for one or two)
-        const uint64_t idle  = __ballot(state == ST_IDLE || state == ST_DONE);
+        const uint64_t idle  = __builtin_amdgcn_ballot_w64(state == ST_IDLE || state == ST_DONE); // (__ballot goes through a 0/1 register)
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if ((exhausted && nidle == 64u) || (!exhausted && nidle >= refill_min)) {
             if (!TAIL && state == ST_DONE) {
@@ -1635,8 +1635,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         }
 
         bool           pop = false, fin = false;
-        const uint32_t nI = (uint32_t)__popcll(__ballot(state == ST_INNER));
-        const uint32_t nS = TAIL ? (uint32_t)__popcll(__ballot(state == ST_SHADE)) : 0u;
+        const uint32_t nI = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == ST_INNER));
+        const uint32_t nS = TAIL ? (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == ST_SHADE)) : 0u;
         const uint32_t nL = 64u - nidle - nI - nS;
         const bool     doLeaf  = TAIL ? (nL >= leaf_min || (nI == 0u && nL != 0u)) : (nL >= leaf_min || nI == 0u);
         const bool     doInner = nI >= inner_min || !doLeaf;
