@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...)
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
 enum { K_OVERLAP, K_SORT_DEPTH, K_SORT_MIN, K_SORT_EVERY, K_TAIL_MAX, K_TAIL_SHADE_MIN, K_JUMP_TABLE, K_RAYGEN_LEAN, K_EARLY_MISS, K_FAST_DIV,
-       K_BAND_TILES, K_TRACE_CHUNK, K_AHEAD, K_COUNT };
+       K_BAND_TILES, K_TRACE_CHUNK, K_AHEAD, K_TILE_INTERLEAVE, K_COUNT };
 struct Knob {
     const char* name;
     long long   dflt, value;
@@ -90,6 +90,7 @@ static Knob g_knobs[K_COUNT] = {
     {"BAND_TILES", 1, 0},         // 0: 32 x 32 path tiles under the band split too
     {"TRACE_CHUNK", 0, 0},        // rays per work grab of the closest-hit kernel; 0 = by queue length
     {"AHEAD", 1, 0},              // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
+    {"TILE_INTERLEAVE", 1, 0},    // 0: a slab's rows of path tiles are queued top to bottom (1: dealt out to the eight parts of the queue in turn)
 };
 static std::once_flag g_knobs_once;
 static void knobs_init()
@@ -935,6 +936,8 @@ struct FrameGeom {
     uint32_t     jump_b[4];
     // fast != 0: every index below fits 32 bits and the divisions go through these (geom_finish fills them)
     uint32_t fast, h_edge, w_edge;
+    uint32_t il_q; // != 0: the first 8 * il_q rows of tiles are dealt out to the eight parts of the queue in turn (geom_finish)
+    FastDiv  fd_il;
     FastDiv  fd_ns, fd_w, fd_band, fd_trow, fd_th[2], fd_tw[2]; // n_samples, width, band_rows, width * tile_h, tile * {tile_h, h_edge}, {tile, w_edge}
 };
 
@@ -942,6 +945,17 @@ struct FrameGeom {
 static void geom_finish(FrameGeom& g)
 {
     g.fast = 0;
+    g.il_q = 0;
+    // The closest-hit kernel cuts a queue into eight contiguous parts, one per XCD (part_begin).  With the rows of tiles in
+    // image order an XCD's part is one horizontal eighth of the picture, and the eighths that hold the model take several
+    // times longer than those that hold ground and sky: the XCDs that finish early go on with the others' parts, away from
+    // their own L2's contents, and the launch ends on the slow eighths' last rays.  Dealt out in turn — queue position
+    // k * 8 + p's row of tiles goes to part p — every part holds rows from all over the picture: 10.8 -> 10.0 ms for the
+    // camera rays' pass of the bench frame.  A permutation of the path order only: frames are the same, bit for bit.
+    if (g.tile && g.tile_h && knob(K_TILE_INTERLEAVE) != 0) {
+        g.il_q = g.slab_rows / g.tile_h / 8;
+        if (g.il_q) g.fd_il = fastdiv_gen(g.il_q);
+    }
     if (knob(K_FAST_DIV) == 0) return; // the tests compare the two
     if ((uint64_t)g.width * g.height >= (1ull << 32) || g.n_samples == 0 || g.width == 0) return;
     g.fd_ns   = fastdiv_gen(g.n_samples);
@@ -997,8 +1011,12 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
     const uint32_t W = g.width, R = g.slab_rows, T = g.tile, TH = g.tile_h;
     if (g.fast) {
         const uint32_t jj  = (uint32_t)j;
-        const uint32_t tr  = fdiv(jj, g.fd_trow);
+        uint32_t       tr  = fdiv(jj, g.fd_trow);
         const uint32_t rem = jj - tr * (W * TH);
+        if (g.il_q && tr < 8u * g.il_q) {
+            const uint32_t part = fdiv(tr, g.fd_il);
+            tr = (tr - part * g.il_q) * 8u + part;
+        }
         const uint32_t h   = min(TH, R - tr * TH); // TH, or h_edge in the last row of tiles
         const FastDiv  fh  = h != TH ? g.fd_th[1] : g.fd_th[0];
         const uint32_t tc  = fdiv(rem, fh);
@@ -1008,8 +1026,9 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
         const uint32_t rr  = fdiv(r2, fw);
         return (uint64_t)(tr * TH + rr) * W + tc * T + (r2 - rr * w);
     }
-    const uint32_t tr = (uint32_t)(j / ((uint64_t)W * TH));
+    uint32_t       tr = (uint32_t)(j / ((uint64_t)W * TH));
     const uint32_t rem = (uint32_t)(j - (uint64_t)tr * W * TH);
+    if (g.il_q && tr < 8u * g.il_q) tr = (tr % g.il_q) * 8u + tr / g.il_q;
     const uint32_t h   = min(TH, R - tr * TH);
     const uint32_t tc  = rem / (T * h);
     const uint32_t r2  = rem - tc * T * h;

@@ -624,6 +624,27 @@ def test_passes_queued_ahead_of_the_host_change_nothing(built_scenes, device_sce
             assert got[2]["rays_early_miss"] == ref[2]["rays_early_miss"], env
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,spp,depth,band", [("dragon1", 640, 360, 8, 8, None), ("dragon1", 640, 360, 8, 4, (8, 1, 2)), ("materials", 333, 301, 4, 6, None), ("teapot", 1920, 1080, 1, 2, None)])
+def test_tile_rows_dealt_out_to_the_queue_parts_change_nothing(built_scenes, device_scenes, tune, scene, w, h, spp, depth, band):
+    """The rows of path tiles of a slab are queued so that each of the eight parts of the queue (one per XCD) holds rows
+    from all over the picture (knob TILE_INTERLEAVE).  Only the order of the paths changes: frames, rays per depth and
+    shaded hits equal those of the top-to-bottom order bit for bit — whole frames, a band share, a frame whose last row of
+    tiles is cut, with the fast index divisions and without."""
+    sc, ds = built_scenes(scene), device_scenes(scene)
+    p = hip.make_params(w, h, spp, depth, seed=(31, 32), band=band)
+    out = {}
+    for name, env in (("rows", {"RTX_TILE_INTERLEAVE": "0"}), ("dealt", {}), ("dealt_plain_div", {"RTX_FAST_DIV": "0"}), ("dealt_small_slabs", {})):
+        tune(env)
+        q = hip.make_params(w, h, spp, depth, seed=(31, 32), band=band, max_paths_in_flight=(w * spp * 70 if name == "dealt_small_slabs" else 0))
+        out[name] = ds.render(sc.rtx_camera(), q)
+    ref = out["rows"]
+    for name, (bgr, acc, st) in out.items():
+        assert np.array_equal(bgr, ref[0]) and same_bits(acc, ref[1]), name
+        assert st["rays_at_depth"] == ref[2]["rays_at_depth"] and st["hits_shaded"] == ref[2]["hits_shaded"], name
+    assert p is not None
+
+
 def test_compact_textures_are_lossless(built_scenes, device_scenes):
     """SURVEY §8f-3, compact texture formats.  A texture whose channels take at most 256 distinct values (every imported
     BMP: sRGBToLinear(byte / 255), texture.c:15-47) lives on the device as 3 bytes per texel + a palette of the original
