@@ -90,7 +90,7 @@ static Knob g_knobs[K_COUNT] = {
     {"BAND_TILES", 1, 0},         // 0: 32 x 32 path tiles under the band split too
     {"TRACE_CHUNK", 0, 0},        // rays per work grab of the closest-hit kernel; 0 = by queue length
     {"AHEAD", 1, 0},              // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
-    {"TILE_INTERLEAVE", 1, 0},    // 0: a slab's rows of path tiles are queued top to bottom (1: dealt out to the eight parts of the queue in turn)
+    {"TILE_INTERLEAVE", 4096, 0}, // camera pass: the queue's eight parts (one per XCD) are runs of this many rays dealt out in turn; 0: its eighths
 };
 static std::once_flag g_knobs_once;
 static void knobs_init()
@@ -936,8 +936,6 @@ struct FrameGeom {
     uint32_t     jump_b[4];
     // fast != 0: every index below fits 32 bits and the divisions go through these (geom_finish fills them)
     uint32_t fast, h_edge, w_edge;
-    uint32_t il_q; // != 0: the first 8 * il_q rows of tiles are dealt out to the eight parts of the queue in turn (geom_finish)
-    FastDiv  fd_il;
     FastDiv  fd_ns, fd_w, fd_band, fd_trow, fd_th[2], fd_tw[2]; // n_samples, width, band_rows, width * tile_h, tile * {tile_h, h_edge}, {tile, w_edge}
 };
 
@@ -945,17 +943,6 @@ struct FrameGeom {
 static void geom_finish(FrameGeom& g)
 {
     g.fast = 0;
-    g.il_q = 0;
-    // The closest-hit kernel cuts a queue into eight contiguous parts, one per XCD (part_begin).  With the rows of tiles in
-    // image order an XCD's part is one horizontal eighth of the picture, and the eighths that hold the model take several
-    // times longer than those that hold ground and sky: the XCDs that finish early go on with the others' parts, away from
-    // their own L2's contents, and the launch ends on the slow eighths' last rays.  Dealt out in turn — queue position
-    // k * 8 + p's row of tiles goes to part p — every part holds rows from all over the picture: 10.8 -> 10.0 ms for the
-    // camera rays' pass of the bench frame.  A permutation of the path order only: frames are the same, bit for bit.
-    if (g.tile && g.tile_h && knob(K_TILE_INTERLEAVE) != 0) {
-        g.il_q = g.slab_rows / g.tile_h / 8;
-        if (g.il_q) g.fd_il = fastdiv_gen(g.il_q);
-    }
     if (knob(K_FAST_DIV) == 0) return; // the tests compare the two
     if ((uint64_t)g.width * g.height >= (1ull << 32) || g.n_samples == 0 || g.width == 0) return;
     g.fd_ns   = fastdiv_gen(g.n_samples);
@@ -1011,12 +998,8 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
     const uint32_t W = g.width, R = g.slab_rows, T = g.tile, TH = g.tile_h;
     if (g.fast) {
         const uint32_t jj  = (uint32_t)j;
-        uint32_t       tr  = fdiv(jj, g.fd_trow);
+        const uint32_t tr  = fdiv(jj, g.fd_trow);
         const uint32_t rem = jj - tr * (W * TH);
-        if (g.il_q && tr < 8u * g.il_q) {
-            const uint32_t part = fdiv(tr, g.fd_il);
-            tr = (tr - part * g.il_q) * 8u + part;
-        }
         const uint32_t h   = min(TH, R - tr * TH); // TH, or h_edge in the last row of tiles
         const FastDiv  fh  = h != TH ? g.fd_th[1] : g.fd_th[0];
         const uint32_t tc  = fdiv(rem, fh);
@@ -1026,9 +1009,8 @@ DEV uint64_t slab_pixel(const FrameGeom& g, uint64_t j)
         const uint32_t rr  = fdiv(r2, fw);
         return (uint64_t)(tr * TH + rr) * W + tc * T + (r2 - rr * w);
     }
-    uint32_t       tr = (uint32_t)(j / ((uint64_t)W * TH));
+    const uint32_t tr = (uint32_t)(j / ((uint64_t)W * TH));
     const uint32_t rem = (uint32_t)(j - (uint64_t)tr * W * TH);
-    if (g.il_q && tr < 8u * g.il_q) tr = (tr % g.il_q) * 8u + tr / g.il_q;
     const uint32_t h   = min(TH, R - tr * TH);
     const uint32_t tc  = rem / (T * h);
     const uint32_t r2  = rem - tc * T * h;
@@ -1199,6 +1181,7 @@ struct TailArgs {
     uint32_t            max_depth;
     unsigned long long* counts;   // [d]: rays traced at depth d beyond depth0's own; [RTX_MAX_DEPTH]: paths shaded
     uint32_t            shade_min; // lanes that must wait before the shade block runs
+    uint32_t            il_len;   // != 0: parts are not eighths of the queue but rows of il_len rays dealt out in turn (see the grab loop)
     const unsigned long long* n_dev; // not null: the queue's length is read here (the pass was launched before the host knew it; `n` is an upper bound)
 };
 
@@ -1470,6 +1453,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         n = *ta.n_dev;
         if ((tune >> 26) & 1u) chunk = n >= (64ull << 20) ? 160u : 64u; // launch_trace's choice, made here
     }
+    // interleaved parts: rows of `il` rays (a multiple of the grab); 0 = the parts are eighths
+    const uint32_t il = ta.il_len / chunk * chunk;
     // Block scheduling (wave-uniform): the INNER and LEAF blocks cost ~60 and ~90 vector instructions whatever
     // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
     // enough lanes wait for it (or nothing else can run); lanes in the other state simply keep their place.
@@ -1580,16 +1565,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 // (Grabs of at most 128 rays: with 1024-ray grabs a launch ended with some waves a whole grab behind the
                 // others — 104 -> 95 ms per frame; smaller ones cost the primary pass more in atomics than they balance.
                 // Shrinking the grabs as a part drains was no better than the fixed size.)
+                //
+                // Interleaved parts (il != 0: the camera pass, see render_device_impl): the queue is cut into runs of il rays
+                // and run k * 8 + p belongs to part p.
                 while (parts_left > 0) {
-                    const uint64_t     pb = part_begin(n, part), pe = part_begin(n, part + 1);
                     unsigned long long base = 0;
                     const uint64_t     grab = chunk;
                     if (lane == 0) base = atomicAdd(work + 8 * part, (unsigned long long)chunk);
-                    base = wave_bcast_u64(base) + pb;
-                    if (base < pe) {
-                        next = base;
-                        end  = base + grab < pe ? base + grab : pe;
-                        break;
+                    base = wave_bcast_u64(base);
+                    if (il) {
+                        // (il is a multiple of the grab, so a grab never crosses a row's end; offsets past 2^32 are past the queue)
+                        const uint32_t v = (uint32_t)min(base, (unsigned long long)0xFFFFFFFFu), r = v / il;
+                        const uint64_t at = ((uint64_t)r * 8u + part) * il + (v - r * il);
+                        if (at < n) {
+                            next = at;
+                            end  = at + grab < n ? at + grab : n;
+                            break;
+                        }
+                    } else {
+                        const uint64_t pb = part_begin(n, part), pe = part_begin(n, part + 1);
+                        base += pb;
+                        if (base < pe) {
+                            next = base;
+                            end  = base + grab < pe ? base + grab : pe;
+                            break;
+                        }
                     }
                     part = (part + 1) & 7u;
                     parts_left--;
@@ -2529,7 +2529,7 @@ static int resident_blocks(rtx_scene* sc, const TraceKernel& k, unsigned* out)
 
 static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uint64_t n, uint32_t* d_hits, uint64_t hstride, hipStream_t st,
                         bool count, uint64_t* d_counters, bool literal, unsigned long long* work = nullptr, bool bounce_rays = false,
-                        const TailArgs* tail = nullptr, const unsigned long long* n_dev = nullptr)
+                        const TailArgs* tail = nullptr, const unsigned long long* n_dev = nullptr, uint64_t il_len = 0)
 {
     // n_dev: the queue's length is still on the device; n is an upper bound (flat kernels only: render_device_impl checks)
     if (n == 0) return RTX_OK;
@@ -2570,7 +2570,8 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     memset(&ta, 0, sizeof ta);
     if (tail) ta = *tail;
     if (n_dev && variant < 2) return fail(RTX_E_INVALID, "this closest-hit kernel takes the queue's length from the host");
-    ta.n_dev = n_dev;
+    ta.n_dev  = n_dev;
+    ta.il_len = variant >= 2 && il_len < (1ull << 31) ? (uint32_t)il_len : 0u;
     hipLaunchKernelGGL(tk.kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
                        tune | (bounce_rays && !count ? 1u << 25 : 0u) | (n_dev && knob(K_TRACE_CHUNK) <= 0 ? 1u << 26 : 0u), ta);
     HIPCHECK(hipGetLastError());
@@ -2934,6 +2935,14 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     auto soa = [&](const Lane& a, int b) { return Queue{a.qb[b], cap, 1}; };
     auto aos = [&](const Lane& a, int b) { return Queue{a.qb[b], 1, Q_RECORD}; };
 
+    // The camera pass's queue is in image order (tiles).  Cut into eighths — one per XCD — the eighths of the picture that hold
+    // the model take several times longer than those that hold ground and sky; the XCDs that finish early go on with the
+    // others' parts and the pass ends on the slow eighths' last rays.  Runs of 4096 rays (one pixel block of a tile) dealt out
+    // to the parts in turn give every XCD a share of every region: 10.7 -> 10.0 ms for the bench frame's camera pass (sweep:
+    // 64 k rays 10.3, 16 k 10.1, 4 k 10.0, 1 k 10.0).  The bounce passes keep their eighths: interleaved, the first bounce
+    // (whose queue is in image order too) lost 0.6 ms, and the binned queues' order IS their locality.  Only which wave
+    // traces which ray changes; frames are the same bit for bit (test_tile_rows_dealt_out...).
+    auto il_len = [&](const Lane&) -> uint64_t { return (uint64_t)std::max(0ll, knob(K_TILE_INTERLEAVE)); };
     auto launch_binning = [&](Lane& a, uint64_t n, const unsigned long long* n_dev, Queue from, Queue to) {
         uint32_t* chunk = a.bin_cnt + (1u << BIN_BITS);
         hipLaunchKernelGGL(k_bin_scan, dim3(BIN_CHUNKS), dim3(1024), 0, a.s, a.bin_cnt, chunk);
@@ -2949,7 +2958,8 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
         int lrc = RTX_OK, r = RTX_OK;
         if (!a.ahead) { // (else: queued behind the previous depth's shade pass)
             r = timed(1, depth, a.s, [&] {
-                lrc = launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0);
+                lrc = launch_trace(sc, a.qin.base, a.qin.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, depth > 0, nullptr, nullptr,
+                                   depth == 0 ? il_len(a) : 0);
             });
             if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
         }
@@ -2977,7 +2987,8 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
                 nq = aos(a, a.cur);
             }
             r = timed(1, depth + 1, a.s, [&] {
-                lrc = launch_trace(sc, nq.base, nq.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, true, nullptr, a.d_cnt);
+                lrc = launch_trace(sc, nq.base, nq.es == 1 ? cap : 0, a.n, a.hits.base, cap, a.s, count, sc->d_counters, literal, a.work, true, nullptr, a.d_cnt,
+                                   0);
             });
             if (r != RTX_OK || lrc != RTX_OK) return r != RTX_OK ? r : lrc;
             a.ahead = true;

@@ -627,14 +627,14 @@ def test_passes_queued_ahead_of_the_host_change_nothing(built_scenes, device_sce
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,w,h,spp,depth,band", [("dragon1", 640, 360, 8, 8, None), ("dragon1", 640, 360, 8, 4, (8, 1, 2)), ("materials", 333, 301, 4, 6, None), ("teapot", 1920, 1080, 1, 2, None)])
 def test_tile_rows_dealt_out_to_the_queue_parts_change_nothing(built_scenes, device_scenes, tune, scene, w, h, spp, depth, band):
-    """The rows of path tiles of a slab are queued so that each of the eight parts of the queue (one per XCD) holds rows
-    from all over the picture (knob TILE_INTERLEAVE).  Only the order of the paths changes: frames, rays per depth and
-    shaded hits equal those of the top-to-bottom order bit for bit — whole frames, a band share, a frame whose last row of
-    tiles is cut, with the fast index divisions and without."""
+    """The camera pass's queue is handed to the XCDs in runs of 4096 rays dealt out in turn instead of in eighths (knob
+    TILE_INTERLEAVE).  Only which wave traces which ray changes: frames, rays per depth and shaded hits equal those of the
+    eighths bit for bit — whole frames, a band share, odd sizes, other run lengths, slabs smaller than a run."""
     sc, ds = built_scenes(scene), device_scenes(scene)
     p = hip.make_params(w, h, spp, depth, seed=(31, 32), band=band)
     out = {}
-    for name, env in (("rows", {"RTX_TILE_INTERLEAVE": "0"}), ("dealt", {}), ("dealt_plain_div", {"RTX_FAST_DIV": "0"}), ("dealt_small_slabs", {})):
+    for name, env in (("rows", {"RTX_TILE_INTERLEAVE": "0"}), ("dealt", {}), ("dealt_100", {"RTX_TILE_INTERLEAVE": "100"}), ("dealt_huge", {"RTX_TILE_INTERLEAVE": "50000000"}),
+                      ("dealt_small_slabs", {})):
         tune(env)
         q = hip.make_params(w, h, spp, depth, seed=(31, 32), band=band, max_paths_in_flight=(w * spp * 70 if name == "dealt_small_slabs" else 0))
         out[name] = ds.render(sc.rtx_camera(), q)
