@@ -1999,16 +1999,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
 }
 
 // Material_Bounce for every ray of the queue + compaction of the survivors into `qout`
-// (1024-thread blocks: the two counters are bumped once per block.  With 256-thread blocks and a
+// (Large blocks: the two counters are bumped once per block.  With 256-thread blocks and a
 // per-wave atomic the 2.6 M same-address atomics of a 1080p/64 spp pass, ~12 ns each, WERE the kernel's
 // run time — rocprof: 6 % VALU busy, 84 % of wave time waiting.)
 #ifndef SHADE_BLOCK
-#define SHADE_BLOCK 1024
+#define SHADE_BLOCK 512 // (round 2, same box: 1024 threads 12.47 ms of shade per frame, 512: 12.28, 384: 13.8, 256: 14.9)
+#endif
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 8 // waves per SIMD the shade pass is compiled for (64 registers)
 #endif
 DEV uint32_t ray_bin(const SceneDev& S, f3 o, f3 d);
 DEV uint32_t wave_group_add(uint32_t* counters, uint32_t key, bool active, uint32_t& base);
-// (waves_per_eu(8): at most 64 VGPRs, so that two 1024-thread blocks share a CU)
-__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
+// (waves_per_eu(8): at most 64 VGPRs, 32 waves per CU; 6 waves per SIMD with 80 registers: +0.5 ms, 4 with 128: +4.4 ms)
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES))) void k_shade(SceneDev S, Queue qin, Hits hits, uint64_t n, Queue qout,
                                                        unsigned long long* out_count, unsigned long long* shaded_count,
                                                        float* __restrict__ result, uint64_t rcap, int last,
                                                        uint32_t* __restrict__ bin_cnt, uint2* __restrict__ bin_keys, FrameGeom g,
