@@ -11,7 +11,7 @@ import pytest
 
 from oracle import binding as O
 from raytracer_amd import hip
-from util import bits, golden
+from util import bits, golden, random_scene
 
 FIELDS = ("t", "position", "normal", "uv")
 
@@ -77,6 +77,27 @@ def test_culled_equals_literal_on_awkward_rays(built_scenes):
     a, b = O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True), O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True, cull=cull)
     _same(a, b)
     assert b["visits"][3] == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_culled_equals_literal_on_random_scenes(seed):
+    """Seeded soups — 1 to 3000 triangles from slivers to scene-spanning ones, degenerate and duplicate ones, spheres,
+    planes — and rays that start on primitives, on vertices, on the bounds, and run along axes and edges: the replay of
+    the culled walk (boxes, folded cut-off nodes and all) returns the literal recursion's hits bit for bit."""
+    from raytracer_amd import scenes
+    lines, o, d = random_scene(seed)
+    sc = scenes.build(lines)
+    try:
+        cull = hip.cull_data(sc.desc)
+        lit = O.trace(sc.desc, o, d, unit_dir=True)
+        cul = O.trace(sc.desc, o, d, unit_dir=True, cull=cull)
+        _same(lit, cul)
+        if seed % 6 >= 2 or seed % 3 >= 1:  # (a lone triangle or two are rarely hit)
+            assert (lit["prim_id"] != 0xFFFFFFFF).sum() > len(o) // 100
+        if seed % 6 >= 3:
+            assert cul["visits"][3] > 0 and cul["visits"][:3].sum() < lit["visits"].sum()  # (it does cull on the larger ones)
+    finally:
+        sc.close()
 
 
 def test_boxes_contain_their_primitives(built_scenes):

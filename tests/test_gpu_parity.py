@@ -16,7 +16,7 @@ import pytest
 
 from oracle import binding as O
 from raytracer_amd import hip
-from util import GOLDEN, golden, psnr, same_bits, same_values, ulp_diff
+from util import GOLDEN, golden, psnr, random_scene, same_bits, same_values, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -665,3 +665,43 @@ def test_compact_textures_are_lossless(built_scenes, device_scenes):
         p = hip.make_params(200, 112, 4, 16, seed=(5, 9))
         a, b = compact.render(sc.rtx_camera(), p), plain.render(sc.rtx_camera(), p)
         assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1]) and a[2]["rays_at_depth"] == b[2]["rays_at_depth"]
+
+
+CULLED_SEEDS = {0, 1, 2, 3, 4, 7, 8, 9, 10}  # the soups whose default kernel is the culled walk and culls something (from a run)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_match_the_oracle(seed):
+    """The seeded soups of tests/util.py (degenerate, duplicate, huge and tiny triangles, spheres, planes; rays on
+    primitives, vertices and bounds, along axes and edges): the default kernel (culled, folded, cooperative) and the
+    literal kernel return the oracle's hits bit for bit, and visit the nodes and primitives the CPU replays visit."""
+    from raytracer_amd import scenes
+    lines, o, d = random_scene(seed)
+    sc = scenes.build(lines)
+    culled_kernels = 0
+    try:
+        with hip.DeviceScene(sc.desc, 0) as ds:
+            want = O.trace(sc.desc, o, d, unit_dir=True)
+            for flags in (0, hip.RTX_TRACE_LITERAL):
+                got = ds.trace_closest(o, d, flags=hip.RTX_TRACE_UNIT_DIR | hip.RTX_RENDER_COUNT_VISITS | flags)
+                assert np.array_equal(got["prim_id"], want["prim_id"]), flags
+                hit = want["prim_id"] != 0xFFFFFFFF
+                assert np.array_equal(got["front"][hit], want["front"][hit])
+                for k in ("t", "position", "normal"):
+                    assert same_bits(got[k][hit], want[k][hit]), (k, flags)
+                s = got["stats"]
+                # (where a scene's pads exceed its triangles rtx_scene_create makes the literal walk the default, DESIGN §5:
+                # the soups with scene-spanning triangles; it reports no culled box then)
+                if flags or s["visits_culled"] == 0:
+                    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == want["visits"].tolist()
+                else:
+                    rep = O.trace(sc.desc, o, d, unit_dir=True, cull=hip.cull_data(sc.desc))["visits"]
+                    assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == rep.tolist()[:3]
+                    culled_kernels += 1
+    finally:
+        sc.close()
+    assert culled_kernels == (1 if seed in CULLED_SEEDS else 0), "which soups run the culled kernel changed: update CULLED_SEEDS"
+
+
+
