@@ -699,6 +699,12 @@ def test_random_scenes_match_the_oracle(seed):
                     rep = O.trace(sc.desc, o, d, unit_dir=True, cull=hip.cull_data(sc.desc))["visits"]
                     assert [s["visits_inner"], s["visits_leaf"], s["visits_prim"]] == rep.tolist()[:3]
                     culled_kernels += 1
+            # and a frame of primary visibility (depth 1: sky where nothing is hit, black elsewhere) against the oracle's,
+            # byte for byte: camera rays, closest hit, sky lookup and the accumulation involve no libm
+            p = hip.make_params(96, 64, 3, 1, seed=(seed, 77))
+            bgr, acc, st = ds.render(sc.rtx_camera(), p)
+            cum, obgr, rays = O.render(sc.desc, sc.rtx_camera(), p, threads=4)
+            assert same_values(acc, cum) and np.array_equal(bgr, obgr) and st["rays_total"] == int(rays.sum()) == 96 * 64 * 3
     finally:
         sc.close()
     assert culled_kernels == (1 if seed in CULLED_SEEDS else 0), "which soups run the culled kernel changed: update CULLED_SEEDS"
