@@ -195,7 +195,7 @@ int         rtx_device_count(int* count);
 
 /* ---- tuning knobs.  The render loop's switches (most exist so that a test can render a frame both ways and compare the
  * bits; none changes a result) live in one process-wide table: OVERLAP, SORT_DEPTH, SORT_MIN, SORT_EVERY, TAIL_MAX,
- * TAIL_SHADE_MIN, JUMP_TABLE, RAYGEN_LEAN, EARLY_MISS, FAST_DIV, BAND_TILES, TRACE_CHUNK.  The environment
+ * TAIL_SHADE_MIN, JUMP_TABLE, RAYGEN_LEAN, EARLY_MISS, FAST_DIV, BAND_TILES, TRACE_CHUNK, AHEAD, TILE_INTERLEAVE.  The environment
  * (RTX_<NAME>) is read ONCE, at first use, for the defaults; no entry point reads the environment per call.  Set a knob
  * only while no call is in flight.  No counterpart in the reference (its switches are compile-time, src/common/config.h). ---- */
 int  rtx_tune_set(const char* name, long long value);
