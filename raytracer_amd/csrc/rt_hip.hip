@@ -1381,7 +1381,8 @@ __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* 
 // predicated store), and the leaf keeps the NEXT leaf reference in flight while testing the
 // current primitive.
 // ---------------------------------------------------------------------------------------------
-enum { ST_IDLE = 0, ST_INNER = 1, ST_LEAF = 2, ST_SHADE = 3, ST_DONE = 4 }; // DONE: walk finished, hit record not written yet
+// (DONE: walk finished, hit record not written yet.  "Free for a new ray" — DONE or IDLE — is one comparison: state >= ST_DONE)
+enum { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3, ST_IDLE = 4 };
 // One wave per block: the waves share nothing, and a block's LDS and wave slots come free the moment ITS wave
 // has finished its last ray — with 4-wave blocks the slowest of four decided, which kept the next kernel's
 // blocks (the other lane of rtx_render_device, or simply the shade pass) out of the CU during the tail.
@@ -1467,6 +1468,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
 
     uint64_t next = 0, end = 0; // wave-uniform
     bool     exhausted = false; // wave-uniform
+    uint32_t refill_at = refill_min; // wave-uniform: free lanes at which the wave stops to refill (64 once the queue has run dry: then to leave)
     uint32_t part      = xcc_id(), parts_left = 8; // wave-uniform
     int      state     = ST_IDLE;
 
@@ -1546,17 +1548,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     for (;;) {
         // (a lane whose walk has finished keeps its hit — DONE — until the wave next refills or ends: the record's four
         // stores and the merge with the unbounded list then run for many lanes at once instead of for one or two)
-        const uint64_t idle  = __builtin_amdgcn_ballot_w64(state == ST_IDLE || state == ST_DONE); // (__ballot goes through a 0/1 register)
+        // (The loop's scheduling is scalar code, and at this kernel's issue rate a scalar instruction costs about half a vector
+        // one — 40 of them per iteration, added for the measurement, cost 5.7 ms per frame —, so the common path through here is
+        // one ballot, one count and one comparison: refill_at is refill_min, or 64 once the queue has run dry.)
+        const uint64_t idle  = __builtin_amdgcn_ballot_w64(state >= ST_DONE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
-        if ((exhausted && nidle == 64u) || (!exhausted && nidle >= refill_min)) {
+        if (nidle >= refill_at) {
             if (!TAIL && state == ST_DONE) {
                 if (COOP) take_best();
                 write_hit(best, bestT, bu, bv);
                 state = ST_IDLE;
             }
-        }
-        if (exhausted && nidle == 64u) break;
-        if (!exhausted && nidle >= refill_min) {
+            if (exhausted) break; // (all 64 lanes are free and there is nothing left to load)
             if (next >= end) {
                 // The queue is cut into 8 contiguous parts, one per XCD (work[8 * part] = rays handed out of that
                 // part): the waves of an XCD drain their own part front to back, so the rays resident on an XCD
@@ -1594,7 +1597,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     part = (part + 1) & 7u;
                     parts_left--;
                 }
-                if (parts_left == 0) exhausted = true;
+                if (parts_left == 0) exhausted = true, refill_at = 64u;
             }
             if (!exhausted) {
                 const uint32_t avail = (uint32_t)(end - next);
@@ -1650,13 +1653,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                 }
                 next += take;
             }
-            continue;
+            // (no `continue`: the lanes just loaded take their first step in this pass through the loop)
         }
 
         bool           pop = false, fin = false;
         const uint32_t nI = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == ST_INNER));
         const uint32_t nS = TAIL ? (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == ST_SHADE)) : 0u;
-        const uint32_t nL = 64u - nidle - nI - nS;
+        const uint32_t nL = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(state == ST_LEAF));
         const bool     doLeaf  = TAIL ? (nL >= leaf_min || (nI == 0u && nL != 0u)) : (nL >= leaf_min || nI == 0u);
         const bool     doInner = nI >= inner_min || !doLeaf;
         // TAIL: shading runs for a batch of waiting lanes, or when nothing else in the wave can move
