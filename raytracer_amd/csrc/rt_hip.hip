@@ -1889,13 +1889,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         if (pop) {
             if (sp > 0) {
                 sp--;
-                uint2 e;
-                if (sp >= base) {
-                    e = lstk[(sp & (LDS_SLOTS - 1)) * 64];
-                } else { // window empty: take the entry back from scratch
-                    e    = stk[sp];
-                    base = sp;
+                if (sp < base) { // window empty (rare): the entry comes back from scratch into its LDS slot first, so that
+                    lstk[(sp & (LDS_SLOTS - 1)) * 64] = stk[sp]; // the common path is one LDS read, not a generic-address load
+                    base = sp;                                   // with its address selects (a wave's LDS accesses are in order)
                 }
+                const uint2 e = lstk[(sp & (LDS_SLOTS - 1)) * 64];
                 node          = e.x;
                 tMax          = __uint_as_float(e.y);
                 state         = ST_INNER;
