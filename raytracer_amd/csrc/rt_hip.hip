@@ -1823,7 +1823,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
 #endif
                     const float4 b = tp[1];
                     const float  c = *(const float*)(tp + 2);
-                    hitS = Triangle_HitAt(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c), so, sd, RT_EPSILON, sT, tS, uS, vS);
+                    hitS = Triangle_HitAt_straight(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c), so, sd, RT_EPSILON, sT, tS, uS, vS);
                 }
                 if (hitS) {
                     keyS = (unsigned long long)__float_as_uint(tS) << 32 | (lane + 1u);

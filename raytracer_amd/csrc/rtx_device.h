@@ -305,6 +305,22 @@ DEV bool Triangle_HitAt(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tMin, float tMax,
     return true;
 }
 
+// Triangle_HitAt without its early returns: the same operations in the same order, the four rejections of surfaces.c:146-165
+// as one predicate (a NaN falls through each comparison the same way).  For the cooperative leaf block, where 50-odd lanes
+// test different triangles in step: some lane nearly always gets past every rejection, so the early returns skip nothing
+// there — they only cost the scalar instructions and branches that nest the execution masks.
+DEV bool Triangle_HitAt_straight(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tMin, float tMax, float& t, float& u, float& v)
+{
+    const f3    h = vcross(d, e2);
+    const float a = vdot(e1, h);
+    const f3    s = vsub(o, v0);
+    u             = vdot(s, h) / a;
+    const f3 q    = vcross(s, e1);
+    v             = vdot(d, q) / a;
+    t             = vdot(e2, q) / a;
+    return !(fabsf(a) < RT_EPSILON) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && !(t > tMax || t < tMin);
+}
+
 // Triangle_HitAt for two triangles A and B against the same ray, component 0 = A, component 1 = B.  Every
 // arithmetic operation is the one of the scalar routine above, in the same order, on a 2-vector: gfx950 issues
 // v_pk_mul_f32 / v_pk_add_f32 (two IEEE binary32 results per lane and instruction, no fusion with
