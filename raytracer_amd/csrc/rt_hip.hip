@@ -1819,6 +1819,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     const float4* tp = TRI_PTR(S, refS);
                     float4        a  = tp[0];
 #if TRI_WAIT
+                    // (Round 1: a vector-L1 miss is not merged with a miss pending on the same line, so taking the first 16 bytes,
+                    // waiting, and reading the rest from L1 saved two of three L2 requests — worth 9 % while the passes were
+                    // bound by the rate of L2 misses.  Round 2, v24: the kernel is bound by issue and by its own waits, and the
+                    // second wait costs 3.4 ms per frame: 82.1 -> 78.7 ms with the three loads issued together.)
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)::"memory");
 #endif
                     const float4 b = tp[1];

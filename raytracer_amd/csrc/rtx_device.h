@@ -23,7 +23,7 @@
 // the address is only 4-byte aligned when TRI_BYTES is no multiple of 16, which global loads allow
 #define TRI_PTR(S, r) ((const float4*)((const char*)(S).tri + (uint64_t)TRI_BYTES * (r)))
 #ifndef TRI_WAIT
-#define TRI_WAIT 1
+#define TRI_WAIT 0 // 1: take a record's first 16 bytes, wait, read the rest from L1 (see the leaf blocks)
 #endif
 
 #define NODE_WORDS 10 // dwords per record of the culled kernel's node pool
