@@ -26,7 +26,9 @@
 #define TRI_WAIT 0 // 1: take a record's first 16 bytes, wait, read the rest from L1 (see the leaf blocks)
 #endif
 
+#ifndef NODE_WORDS
 #define NODE_WORDS 10 // dwords per record of the culled kernel's node pool
+#endif
 
 #define DEV __device__ __forceinline__
 
