@@ -79,7 +79,7 @@ struct Knob {
 static Knob g_knobs[K_COUNT] = {
     {"OVERLAP", 0, 0},            // 1..3: the assigned pixels go through the bounce loop as 2..4 parts on as many streams
     {"SORT_DEPTH", 2, 0},         // bin the queues that feed depth >= this; 0 = never
-    {"SORT_MIN", 2500000, 0},     // ... if they hold at least this many rays
+    {"SORT_MIN", 1500000, 0},     // ... if they hold at least this many rays
     {"SORT_EVERY", 1, 0},         // ... every k-th eligible depth
     {"TAIL_MAX", TAIL_MAX_DEFAULT, 0}, // longest queue handed to the tail launch; 0 = never
     {"TAIL_SHADE_MIN", 16, 0},    // lanes that wait before the tail launch shades in place
@@ -2845,9 +2845,9 @@ static int render_device_impl(rtx_scene* sc, const rtx_camera* cam, const rtx_re
     if ((rc = workspace(sc, lanes * lane_bytes, &ws)) != RTX_OK) return rc;
     // bin the queues that feed depth >= sort_depth (knob SORT_DEPTH; 0 = never)
     const int   sort_depth = (int)knob(K_SORT_DEPTH);
-    // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~2.5 M rays the closest-hit
+    // binning a queue costs a pass over it plus a fixed ~0.2 ms (histogram scan, launches): below ~1.5 M rays the closest-hit
     // pass it speeds up is too short to pay that back (tools/dbg/bands.py: a rank's share under an 8-way split)
-    const long long bin_min    = knob(K_SORT_MIN); // (4 M before the scatter got cheaper)
+    const long long bin_min    = knob(K_SORT_MIN); // (4 M before the scatter got cheaper, 2.5 M until v25: tools/dbg/share_sortmin.py)
     const int       sort_every = (int)std::max(1ll, knob(K_SORT_EVERY)); // experiments: bin every k-th eligible depth (huge = once)
     if (!sc->h_alive) HIPCHECK(hipHostMalloc((void**)&sc->h_alive, RTX_MAX_LANES * sizeof(unsigned long long)));
     if (lanes > 1 && !sc->ev_fork) HIPCHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
