@@ -1389,6 +1389,14 @@ enum { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3, ST_IDLE = 4 };
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 64
 #endif
+// Block thresholds once a wave's queue has run dry.  Until then a block waits for enough lanes because every instruction it
+// issues competes with five other waves' and new rays keep the lanes full; afterwards the chip empties, an instruction costs
+// nothing, and a lane that waits for three others to reach a leaf only lengthens the launch's last millisecond (same-box A/B,
+// three rounds: whole frame 79.95 -> 79.50 ms, a rank's share at N = 8 15.82 -> 15.39, at N = 64 6.14 -> 5.87; the tail
+// launch's shade threshold lowered the same way changed nothing).
+#ifndef DRAIN_MIN
+#define DRAIN_MIN 1u
+#endif
 #ifndef LDS_SLOTS
 #define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave (16 slots: fewer blocks per CU, 14 % slower)
 #endif
@@ -1459,7 +1467,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     // Block scheduling (wave-uniform): the INNER and LEAF blocks cost ~60 and ~90 vector instructions whatever
     // the number of lanes that need them, and the kernel is VALU-issue bound.  A block therefore runs only when
     // enough lanes wait for it (or nothing else can run); lanes in the other state simply keep their place.
-    const uint32_t leaf_min = tune & 0xFFu, inner_min = (tune >> 8) & 0xFFu, refill_min = (tune >> 16) & 0xFFu;
+    uint32_t       leaf_min = tune & 0xFFu, inner_min = (tune >> 8) & 0xFFu; // (1 and 1 once the queue has run dry: nothing is gained by waiting then)
+    const uint32_t refill_min = (tune >> 16) & 0xFFu;
     // the root's box is tested when a ray is loaded — unless the caller knows the rays start on the scene's surfaces
     // (bounce passes), where that test never fails and the children's tests one step later do its work
     const bool     root_test = !TAIL && !((tune >> 25) & 1u);
@@ -1597,7 +1606,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     part = (part + 1) & 7u;
                     parts_left--;
                 }
-                if (parts_left == 0) exhausted = true, refill_at = 64u;
+                if (parts_left == 0) exhausted = true, refill_at = 64u, leaf_min = DRAIN_MIN, inner_min = DRAIN_MIN;
             }
             if (!exhausted) {
                 const uint32_t avail = (uint32_t)(end - next);
