@@ -33,6 +33,7 @@ def lib():
         L.oracle_trace.argtypes = [dp, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
         L.oracle_trace_culled.argtypes = [dp, C.POINTER(C.c_uint16), f32p, u8p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
         L.oracle_render.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), f32p, u8p, u64p, C.c_int]
+        L.oracle_render_pixels.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, f32p, u64p, C.c_int]
         L.oracle_camera_rays.argtypes = [C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
                                          f32p, f32p, u32p]
         L.oracle_rng_unilateral.argtypes = [C.c_uint64, C.c_uint64, C.c_size_t, f32p]
@@ -78,6 +79,16 @@ def render(desc, cam, params, threads=8, want_bgr=True):
                              _p(rays, C.c_uint64), threads)
     assert rc == 0
     return cum, bgr, rays
+
+
+def render_pixels(desc, cam, params, pixel_index, threads=8):
+    """RenderPixel for a list of pixels of the frame `params` describes: (n, 3) f32 sums, rays per depth."""
+    pi = np.ascontiguousarray(pixel_index, np.uint32)
+    cum = np.zeros((len(pi), 3), np.float32)
+    rays = np.zeros(64, np.uint64)
+    rc = lib().oracle_render_pixels(desc, C.byref(cam), C.byref(params), len(pi), _p(pi, C.c_uint32), _p(cum, C.c_float), _p(rays, C.c_uint64), threads)
+    assert rc == 0
+    return cum, rays
 
 
 def camera_rays(cam, params, pixel_index, sample):

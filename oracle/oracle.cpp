@@ -1211,12 +1211,37 @@ struct RenderJob {
     uint8_t*                 bgr;
     int                      tid, nthreads;
     u64                      rays_at_depth[RTX_MAX_DEPTH + 1];
+    const uint32_t*          pixels; // NULL: the frame's rows
+    size_t                   n_pixels;
 };
 
 static bool row_assigned(const rtx_render_params* p, uint32_t y)
 {
     if (p->band_rows == 0 || p->band_world <= 1) return true;
     return (y / p->band_rows) % p->band_world == p->band_rank;
+}
+
+// RenderPixel's sample loop (renderer.c:98-108) for samples [sb, se) of pixel (xx, yy)
+static Color render_pixel_sum(RenderState* rs, const rtx_camera* cam, const rtx_render_params* p, size_t xx, size_t yy, uint32_t sb, uint32_t se)
+{
+    const size_t image_width = p->width, image_height = p->height;
+    Color        cum_color   = vec(0, 0, 0);
+    for (size_t samples = sb; samples < se; samples++) {
+        u64 pixel = (u64)yy * image_width + xx;
+        Random_Seed(p->seed_lo ^ (pixel * p->spp + samples), p->seed_hi);
+        f32 horizontal_fraction, vertical_fraction;
+        if (p->flags & RTX_RENDER_PIXEL_CENTRES) {
+            horizontal_fraction = (xx + 0.5f) / (f32)(image_width - 1);
+            vertical_fraction   = (yy + 0.5f) / (f32)(image_height - 1);
+        } else {
+            horizontal_fraction = (xx + Random_Unilateral()) / (f32)(image_width - 1);
+            vertical_fraction   = (yy + Random_Unilateral()) / (f32)(image_height - 1);
+        }
+        Ray   ray       = Camera_GetRay(cam, horizontal_fraction, vertical_fraction);
+        Color ray_color = RayColor(rs, &ray, p->max_depth);
+        cum_color       = vadd(cum_color, ray_color);
+    }
+    return cum_color;
 }
 
 static void* render_rows(void* arg)
@@ -1230,25 +1255,18 @@ static void* render_rows(void* arg)
     uint32_t sb = p->sample_begin, se = p->sample_end;
     if (sb == 0 && se == 0) se = p->spp;
     const size_t image_width = p->width, image_height = p->height;
+    if (j->pixels) { // a list of pixels of the frame instead of its rows: entry i -> cum[3 i]
+        for (size_t i = j->tid; i < j->n_pixels; i += j->nthreads) {
+            Color c = render_pixel_sum(&rs, j->cam, p, j->pixels[i] % image_width, j->pixels[i] / image_width, sb, se);
+            j->cum[3 * i + 0] = c.x, j->cum[3 * i + 1] = c.y, j->cum[3 * i + 2] = c.z;
+        }
+        memcpy(j->rays_at_depth, rs.rays_at_depth, sizeof rs.rays_at_depth);
+        return NULL;
+    }
     for (size_t yy = j->tid; yy < image_height; yy += j->nthreads) {
         if (!row_assigned(p, (uint32_t)yy)) continue;
         for (size_t xx = 0; xx < image_width; xx++) { // RenderPixel, renderer.c:88
-            Color cum_color = vec(0, 0, 0);
-            for (size_t samples = sb; samples < se; samples++) {
-                u64 pixel = (u64)yy * image_width + xx;
-                Random_Seed(p->seed_lo ^ (pixel * p->spp + samples), p->seed_hi);
-                f32 horizontal_fraction, vertical_fraction;
-                if (p->flags & RTX_RENDER_PIXEL_CENTRES) {
-                    horizontal_fraction = (xx + 0.5f) / (f32)(image_width - 1);
-                    vertical_fraction   = (yy + 0.5f) / (f32)(image_height - 1);
-                } else {
-                    horizontal_fraction = (xx + Random_Unilateral()) / (f32)(image_width - 1);
-                    vertical_fraction   = (yy + Random_Unilateral()) / (f32)(image_height - 1);
-                }
-                Ray   ray       = Camera_GetRay(j->cam, horizontal_fraction, vertical_fraction);
-                Color ray_color = RayColor(&rs, &ray, p->max_depth);
-                cum_color       = vadd(cum_color, ray_color);
-            }
+            Color  cum_color  = render_pixel_sum(&rs, j->cam, p, xx, yy, sb, se);
             size_t i          = yy * image_width + xx;
             j->cum[3 * i + 0] = cum_color.x, j->cum[3 * i + 1] = cum_color.y, j->cum[3 * i + 2] = cum_color.z;
             if (j->bgr) {
@@ -1263,16 +1281,15 @@ static void* render_rows(void* arg)
     return NULL;
 }
 
-extern "C" int oracle_render(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* p, float* cum_out, uint8_t* bgr_out,
-                             uint64_t* rays_at_depth, int n_threads)
+static int run_render_jobs(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* p, float* cum_out, uint8_t* bgr_out,
+                           uint64_t* rays_at_depth, int n_threads, const uint32_t* pixels, size_t n_pixels)
 {
-    if (!desc || !cam || !p || !cum_out || p->max_depth > RTX_MAX_DEPTH) return -1;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     std::vector<RenderJob> jobs(n_threads);
     std::vector<pthread_t> th(n_threads);
     for (int i = 0; i < n_threads; i++) {
-        jobs[i] = RenderJob{desc, cam, p, cum_out, bgr_out, i, n_threads, {0}};
+        jobs[i] = RenderJob{desc, cam, p, cum_out, bgr_out, i, n_threads, {0}, pixels, n_pixels};
         pthread_attr_t attr;
         pthread_attr_init(&attr);
         pthread_attr_setstacksize(&attr, 16 << 20); // the kd recursion + RayColor recursion are deep
@@ -1285,6 +1302,24 @@ extern "C" int oracle_render(const rtx_scene_desc* desc, const rtx_camera* cam, 
             for (int k = 0; k < RTX_MAX_DEPTH; k++) rays_at_depth[k] += jobs[i].rays_at_depth[k];
     }
     return 0;
+}
+
+extern "C" int oracle_render(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* p, float* cum_out, uint8_t* bgr_out,
+                             uint64_t* rays_at_depth, int n_threads)
+{
+    if (!desc || !cam || !p || !cum_out || p->max_depth > RTX_MAX_DEPTH) return -1;
+    return run_render_jobs(desc, cam, p, cum_out, bgr_out, rays_at_depth, n_threads, NULL, 0);
+}
+
+// RenderPixel for a list of pixels (index y * W + x) of the frame params describes: cum_out[3 i] = the f32 sum of pixel i's samples
+extern "C" int oracle_render_pixels(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* p, size_t n, const uint32_t* pixel_index,
+                                    float* cum_out, uint64_t* rays_at_depth, int n_threads)
+{
+    if (!desc || !cam || !p || !cum_out || !pixel_index || p->max_depth > RTX_MAX_DEPTH) return -1;
+    for (size_t i = 0; i < n; i++)
+        if (pixel_index[i] >= (u64)p->width * p->height) return -1;
+    if (n == 0) return 0;
+    return run_render_jobs(desc, cam, p, cum_out, NULL, rays_at_depth, n_threads, pixel_index, n);
 }
 
 extern "C" int oracle_camera_rays(const rtx_camera* cam, const rtx_render_params* p, size_t n, const uint32_t* pixel_index, const uint32_t* sample,

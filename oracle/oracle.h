@@ -42,6 +42,10 @@ int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const
 int oracle_render(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* params, float* cum_out,
                   uint8_t* bgr_out, uint64_t* rays_at_depth, int n_threads);
 
+/* The same for a list of pixels (y * W + x) of that frame: cum_out[3 i ..] = the f32 sum of pixel_index[i]'s samples. */
+int oracle_render_pixels(const rtx_scene_desc* desc, const rtx_camera* cam, const rtx_render_params* params, size_t n,
+                         const uint32_t* pixel_index, float* cum_out, uint64_t* rays_at_depth, int n_threads);
+
 int oracle_camera_rays(const rtx_camera* cam, const rtx_render_params* params, size_t n, const uint32_t* pixel_index,
                        const uint32_t* sample, float* origin_xyz, float* dir_xyz, uint32_t* rng_state4);
 

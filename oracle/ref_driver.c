@@ -489,6 +489,88 @@ static void mode_render(Scene* scene, size_t W, size_t H, size_t spp, size_t dep
 }
 
 // ---------------------------------------------------------------------------------------------
+// render_pixels: RenderPixel (renderer.c:88-111) for a LIST of pixels of a W x H x spp frame, with the seeding of
+// `render` — Random_Seed(seed_lo ^ (pixel * spp + sample), seed_hi) per camera sample — so that pixel p of this mode is
+// pixel p of the whole frame, at any frame size (the full-size goldens of BASELINE configs 2-5: a few thousand
+// pixels of a 1080p x 64 spp or 4K x 1024 spp frame take seconds where the frame takes hours).
+// in : n x u32 pixel index (y * W + x, y = 0 is the bottom row)
+// out: u32 W, H, spp, depth, n; n x u32 pixel; n x f32[3] cum (r, g, b); n x u8[3] (b, g, r)
+// ---------------------------------------------------------------------------------------------
+typedef struct {
+    Scene* scene;
+    size_t W, H, spp, depth, i0, i1;
+    u64    seed_lo, seed_hi;
+    u32*   pix;
+    f32*   cum;
+    u8*    bgr;
+} PixelJob;
+
+static void* render_pixel_list(void* arg)
+{
+    PixelJob* j = (PixelJob*)arg;
+    for (size_t i = j->i0; i < j->i1; i++) {
+        u64    pixel = j->pix[i];
+        size_t xx = pixel % j->W, yy = pixel / j->W;
+        Color  cum = vec(0, 0, 0);
+        for (size_t s = 0; s < j->spp; s++) {
+            Random_Seed(j->seed_lo ^ (pixel * j->spp + s), j->seed_hi);
+            f32   hf  = (xx + Random_Unilateral()) / (f32)(j->W - 1);
+            f32   vf  = (yy + Random_Unilateral()) / (f32)(j->H - 1);
+            Ray   ray = Camera_GetRay(g_cam, hf, vf);
+            Color c   = RayColor(j->scene, &ray, j->depth);
+            cum       = vadd(cum, c);
+        }
+        Color avg         = vdiv(cum, j->spp);
+        RGB   px          = RGB_FromColor(avg);
+        j->cum[3 * i + 0] = cum.r, j->cum[3 * i + 1] = cum.g, j->cum[3 * i + 2] = cum.b;
+        j->bgr[3 * i + 0] = px.b, j->bgr[3 * i + 1] = px.g, j->bgr[3 * i + 2] = px.r;
+    }
+    return NULL;
+}
+
+static void mode_render_pixels(Scene* scene, size_t W, size_t H, size_t spp, size_t depth, u64 seed_lo, u64 seed_hi,
+                               size_t threads, const char* in, const char* out)
+{
+    FILE* fi = fopen(in, "rb");
+    if (!fi) ABORT("cannot open %s", in);
+    fseek(fi, 0, SEEK_END);
+    size_t n = (size_t)ftell(fi) / 4;
+    fseek(fi, 0, SEEK_SET);
+    u32* pix = (u32*)calloc(n ? n : 1, 4);
+    if (fread(pix, 4, n, fi) != n) ABORT("short read");
+    fclose(fi);
+    for (size_t i = 0; i < n; i++)
+        if (pix[i] >= W * H) ABORT("pixel %u outside the %zu x %zu frame", pix[i], W, H);
+    f32* cum = (f32*)calloc(n * 3 + 1, sizeof(f32));
+    u8*  bgr = (u8*)calloc(n * 3 + 1, 1);
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pthread_t th[64];
+    PixelJob  jobs[64];
+    f64       t0  = now_s();
+    size_t    per = (n + threads - 1) / threads;
+    for (size_t i = 0; i < threads; i++) {
+        jobs[i] = (PixelJob){scene, W, H, spp, depth, MIN(i * per, n), MIN((i + 1) * per, n), seed_lo, seed_hi, pix, cum, bgr};
+        pthread_attr_t attr;
+        pthread_attr_init(&attr);
+        pthread_attr_setstacksize(&attr, 8 * 1024 * 1024);
+        pthread_create(&th[i], &attr, render_pixel_list, &jobs[i]);
+    }
+    for (size_t i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    f64   t1 = now_s();
+    FILE* fd = fopen(out, "wb");
+    if (!fd) ABORT("cannot write %s", out);
+    u32 hdr[5] = {(u32)W, (u32)H, (u32)spp, (u32)depth, (u32)n};
+    put(fd, hdr, sizeof hdr);
+    put(fd, pix, n * 4);
+    put(fd, cum, n * 3 * sizeof(f32));
+    put(fd, bgr, n * 3);
+    fclose(fd);
+    printf("{\"width\": %zu, \"height\": %zu, \"spp\": %zu, \"depth\": %zu, \"pixels\": %zu, \"seconds\": %.6f, \"threads\": %zu}\n",
+           W, H, spp, depth, n, t1 - t0, threads);
+}
+
+// ---------------------------------------------------------------------------------------------
 // flatten: Rtx_Flatten (flatten_ref.c) over the reference's own Scene; every pool dumped for the byte comparison with
 // the product's Scene_Flatten (tests/test_reference_binding.py).
 // file: u32 magic 'RFL1', then the desc's 10 counts (n_nodes n_refs root n_tris n_spheres n_planes n_materials n_textures
@@ -677,6 +759,7 @@ int main(int argc, char** argv)
                 "       ... primary W H spp jitter seed_lo seed_hi step out.bin\n"
                 "       ... trace rays.bin out.bin\n"
                 "       ... render W H spp depth seed_lo seed_hi threads out.bin\n"
+                "       ... render_pixels W H spp depth seed_lo seed_hi threads pixels.bin out.bin\n"
                 "       ... bounce in.bin out.bin\n"
                 "       ... sky in.bin out.bin\n"
                 "       ... flatten out.bin\n"
@@ -707,6 +790,9 @@ int main(int argc, char** argv)
     } else if (!strcmp(mode, "render") && n == 8) {
         mode_render(scene, strtoull(a[0], 0, 0), strtoull(a[1], 0, 0), strtoull(a[2], 0, 0), strtoull(a[3], 0, 0),
                     strtoull(a[4], 0, 0), strtoull(a[5], 0, 0), strtoull(a[6], 0, 0), a[7]);
+    } else if (!strcmp(mode, "render_pixels") && n == 9) {
+        mode_render_pixels(scene, strtoull(a[0], 0, 0), strtoull(a[1], 0, 0), strtoull(a[2], 0, 0), strtoull(a[3], 0, 0),
+                           strtoull(a[4], 0, 0), strtoull(a[5], 0, 0), strtoull(a[6], 0, 0), a[7], a[8]);
     } else if (!strcmp(mode, "bounce") && n == 2) {
         mode_bounce(a[0], a[1]);
     } else if (!strcmp(mode, "sky") && n == 2) {

@@ -29,6 +29,9 @@ from . import assets, host
 
 # the reference's camera and fixtures (src/main.c:332-338, :230-239, :252-257)
 CAMERA = "camera 20 -20 20  0 0 6  0 0 1  40 0 0"
+# the same view through a lens: aperture 2 (lensRadius 1) focused in front of the model, so that Camera_GetRay's offset
+# branch (camera.c:36-46) and a focus distance other than |from - to| are on the path — no BASELINE config uses them
+CAMERA_LENS = "camera 20 -20 20  0 0 6  0 0 1  40 2.0 25"
 LIGHT = ["texture white color 1 1 1", "material light light white 5", "sphere 20 20 10 8 light"]
 
 
@@ -38,8 +41,8 @@ def _rel(path: str) -> str:
 
 def recipe(name: str) -> list:
     """Named configs.  Mesh paths are relative to assets.cache_dir()."""
-    if name == "teapot":  # config 1: teapot, scale 2, origin (0,0,4)
-        return ["aspect 1.7777778", "skybox color 0.5 0.7 1.0", CAMERA, "texture yellow color 0.8 0.6 0.2",
+    if name in ("teapot", "teapotdof"):  # config 1: teapot, scale 2, origin (0,0,4); "teapotdof": through the lens
+        return ["aspect 1.7777778", "skybox color 0.5 0.7 1.0", CAMERA if name == "teapot" else CAMERA_LENS, "texture yellow color 0.8 0.6 0.2",
                 "material body diffuse yellow", "mesh %s body 2 0 0 4" % _rel(assets.obj_path("teapot")), *LIGHT,
                 "texture grey color 0.5 0.5 0.5", "material ground diffuse grey", "plane 0 0 0 0 0 1 ground"]
     if name == "bunny":  # config 2: bunny Lambert+metal, scale 80, sitting on z=0

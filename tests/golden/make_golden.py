@@ -76,10 +76,13 @@ def g_kd():
     print("wrote kd.json")
 
 
-def g_primary():
+def g_primary(only=None):
     W, H = 1920, 1080
-    sums = {}
-    for sc, step in [("teapot", 12), ("bunny", 12), ("pear", 12), ("materials", 12), ("dragon1", 24)]:
+    path = os.path.join(HERE, "primary_checksums.json")
+    sums = json.load(open(path)) if only and os.path.exists(path) else {}
+    for sc, step in [("teapot", 12), ("bunny", 12), ("pear", 12), ("materials", 12), ("dragon1", 24), ("teapotdof", 12)]:
+        if only and sc != only:
+            continue
         f = os.path.join(TMP, "p.bin")
         for jitter, tag in [(0, "A"), (1, "B")]:
             full = ref(sc, "primary", W, H, 1, jitter, 1, 2, 1, f)  # full 1080p: checksums only
@@ -89,7 +92,7 @@ def g_primary():
                                              sha256_t=hashlib.sha256(rec["t"].tobytes()).hexdigest())
             sub = rec.reshape(H, W)[::step, ::step].reshape(-1)
             save("primary_%s_%s.npz" % (sc, tag), rec=sub, step=np.int32(step), width=np.int32(W), height=np.int32(H))
-    json.dump(sums, open(os.path.join(HERE, "primary_checksums.json"), "w"), indent=1)
+    json.dump(sums, open(path, "w"), indent=1)
     print("wrote primary_checksums.json")
 
 
@@ -124,7 +127,9 @@ def ref_render(sc, w, h, spp, depth, lo, hi):
 RENDERS = [("teapot", 96, 54, 8, 8), ("bunny", 96, 54, 8, 8), ("dragon1", 96, 54, 8, 8), ("pear", 96, 54, 8, 16),
            ("materials", 128, 72, 16, 8), ("materials", 64, 36, 4, 1),
            # the bench configuration's sampling (BASELINE configs[2]: 64 spp, depth 8) and config 5's (1024 spp)
-           ("dragon1", 240, 135, 64, 8), ("dragon1", 192, 108, 1024, 8)]
+           ("dragon1", 240, 135, 64, 8), ("dragon1", 192, 108, 1024, 8),
+           # Camera_GetRay with a lens (aperture 2, focus 25): no BASELINE config has one
+           ("teapotdof", 96, 54, 8, 8)]
 
 
 def g_render(only=None):
@@ -137,13 +142,77 @@ def g_render(only=None):
         print(meta)
 
 
+def ref_render_pixels(sc, w, h, spp, depth, lo, hi, pix):
+    fi, fo = os.path.join(TMP, "px_in.bin"), os.path.join(TMP, "px_out.bin")
+    np.ascontiguousarray(pix, "<u4").tofile(fi)
+    meta = ref(sc, "render_pixels", w, h, spp, depth, lo, hi, 8, fi, fo)
+    raw = open(fo, "rb").read()
+    n = len(pix)
+    assert struct.unpack_from("<5I", raw, 0) == (w, h, spp, depth, n)
+    assert np.array_equal(np.frombuffer(raw, "<u4", n, 20), pix)
+    cum = np.frombuffer(raw, "<f4", 3 * n, 20 + 4 * n).reshape(n, 3)
+    bgr = np.frombuffer(raw, np.uint8, 3 * n, 20 + 16 * n).reshape(n, 3)
+    return cum, bgr, meta
+
+
+def sparse_pixels(sc, W, H, n, seed):
+    """n pixels of the W x H frame: half on a jittered grid (ground, sky, light and model in the proportions of the
+    picture), half in the cells of the 1080p primary-ray golden where the kind of the thing hit — model, sphere, plane,
+    nothing — differs from a neighbour's: silhouettes, contact lines and the light's rim."""
+    rng = np.random.default_rng(seed)
+    gx = int(round((n // 2 * W / H) ** 0.5))
+    gy = (n // 2 + gx - 1) // gx
+    ys, xs = np.meshgrid(np.arange(gy), np.arange(gx), indexing="ij")
+    x = ((xs + rng.random(xs.shape)) * W / gx).astype(np.int64).clip(0, W - 1)
+    y = ((ys + rng.random(ys.shape)) * H / gy).astype(np.int64).clip(0, H - 1)
+    grid = (y * W + x).reshape(-1)[: n // 2]
+    g = np.load(os.path.join(HERE, "primary_%s_A.npz" % sc))
+    step, gw, gh = int(g["step"]), int(g["width"]), int(g["height"])
+    ids = g["rec"]["id"].reshape((gh + step - 1) // step, (gw + step - 1) // step)
+    kind = np.where(ids == 0xFFFFFFFF, 0, np.where(ids >= 0x80000000, 1, 2)).astype(np.int64)
+    big = np.bincount(ids[(kind == 2)].astype(np.int64)).argmax() if (kind == 2).any() else -1
+    kind[(kind == 2) & (ids == ids.max(where=kind == 2, initial=0))] = 3  # the light sphere is the last kd object
+    edge = np.zeros_like(kind, bool)
+    edge[:, 1:] |= kind[:, 1:] != kind[:, :-1]
+    edge[1:, :] |= kind[1:, :] != kind[:-1, :]
+    edge[:, :-1] |= edge[:, 1:].copy()
+    edge[:-1, :] |= edge[1:, :].copy()
+    cy, cx = np.nonzero(edge)
+    pick = rng.integers(0, len(cy), n - len(grid))
+    ex = ((cx[pick] * step + rng.integers(-step, step, len(pick))) * W // gw).clip(0, W - 1)
+    ey = ((cy[pick] * step + rng.integers(-step, step, len(pick))) * H // gh).clip(0, H - 1)
+    pix = np.unique(np.concatenate([grid, ey * W + ex]).astype(np.uint32))
+    del big
+    return pix
+
+
+# BASELINE configs 2-5 at their FULL size, a pixel subset each (VERDICT r2 item 2a): the per-path seeding makes pixel p of
+# the list pixel p of the whole frame
+SPARSE = [("bunny", 1920, 1080, 64, 8, 8192), ("dragon1", 1920, 1080, 64, 8, 8192), ("pear", 1920, 1080, 64, 16, 8192),
+          ("dragon1", 3840, 2160, 1024, 8, 1024)]
+
+
+def g_sparse(only=None):
+    for k, (sc, w, h, spp, depth, n) in enumerate(SPARSE):
+        name = "sparse_%s_%dx%d_%dspp_d%d.npz" % (sc, w, h, spp, depth)
+        if only and only not in name:
+            continue
+        pix = sparse_pixels(sc, w, h, n, 31 + k)
+        cum, bgr, meta = ref_render_pixels(sc, w, h, spp, depth, 1, 2, pix)
+        cum2, bgr2, _ = ref_render_pixels(sc, w, h, spp, depth, 3, 4, pix)  # the noise floor of exactly these pixels
+        fin = np.isfinite(cum).all(axis=1) & np.isfinite(cum2).all(axis=1)
+        floor = float(np.sqrt(np.mean((bgr[fin].astype(np.float64) - bgr2[fin].astype(np.float64)) ** 2)))
+        save(name, pix=pix, cum=cum, bgr=bgr, meta=np.array([w, h, spp, depth, 1, 2], np.int64), noise_rmse_8bit=np.float64(floor))
+        print(meta, "noise floor (8 bit, seeds (1,2) vs (3,4)):", floor)
+
+
 def g_noise():
     """CPU-vs-CPU noise floor: the reference against ITSELF with another seed, same scene and sampling.
     Two frames that agree path for path differ by far less than this; two frames that are merely both correct
     differ by about this much.  The numbers go to noise.json; the GPU tests' image bounds cite them."""
     out = {}
     for sc, w, h, spp, depth in [("dragon1", 240, 135, 64, 8), ("dragon1", 96, 54, 8, 8), ("materials", 128, 72, 16, 8), ("bunny", 96, 54, 8, 8),
-                                 ("teapot", 96, 54, 8, 8), ("pear", 96, 54, 8, 16)]:
+                                 ("teapot", 96, 54, 8, 8), ("pear", 96, 54, 8, 16), ("teapotdof", 96, 54, 8, 8)]:
         a_cum, a_bgr, _ = ref_render(sc, w, h, spp, depth, 1, 2)
         b_cum, b_bgr, _ = ref_render(sc, w, h, spp, depth, 3, 4)
         fin = np.isfinite(a_cum).all(axis=2) & np.isfinite(b_cum).all(axis=2)
@@ -202,7 +271,7 @@ def g_sky():
         save("sky_%s.npz" % sc, dirs=d, rgb=np.fromfile(fo, "<f4").reshape(-1, 3))
 
 
-GROUPS = dict(rng=g_rng, kd=g_kd, primary=g_primary, trace=g_trace, render=g_render, bounce=g_bounce, sky=g_sky, noise=g_noise)
+GROUPS = dict(rng=g_rng, kd=g_kd, primary=g_primary, trace=g_trace, render=g_render, bounce=g_bounce, sky=g_sky, noise=g_noise, sparse=g_sparse)
 
 if __name__ == "__main__":
     if not os.path.exists(REF):
@@ -210,5 +279,9 @@ if __name__ == "__main__":
     for g in (sys.argv[1:] or list(GROUPS)):
         if g.startswith("render:"):  # render:<substring of the fixture's name>
             g_render(g[7:])
+        elif g.startswith("sparse:"):
+            g_sparse(g[7:])
+        elif g.startswith("primary:"):  # primary:<scene>
+            g_primary(g[8:])
         else:
             GROUPS[g]()

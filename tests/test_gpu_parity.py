@@ -30,7 +30,7 @@ def tune():
         hip.tune(**knobs)
     yield set_
     hip.tune()
-SCENES = ["teapot", "bunny", "pear", "materials", "dragon1"]
+SCENES = ["teapot", "bunny", "pear", "materials", "dragon1", "teapotdof"]  # teapotdof: the same view through a lens (aperture 2, focus 25): camera.c:36-46
 ULP_TOL = 2
 
 
@@ -178,11 +178,15 @@ def test_skybox_lookup_exact(device_scenes):
 
 RENDERS = ["render_teapot_96x54_8spp_d8", "render_bunny_96x54_8spp_d8", "render_dragon1_96x54_8spp_d8",
            "render_pear_96x54_8spp_d16", "render_materials_128x72_16spp_d8", "render_materials_64x36_4spp_d1",
-           "render_dragon1_240x135_64spp_d8"]
+           "render_dragon1_240x135_64spp_d8", "render_teapotdof_96x54_8spp_d8"]
 NOISE = json.load(open(os.path.join(GOLDEN, "noise.json")))  # the reference against itself with another seed (make_golden.py noise)
 
 
 def _check_frame_vs_reference(bgr, acc, g, spp, noise_key):
+    return _check_pixels_vs_reference(bgr, acc, g["bgr"], g["cum"], spp, NOISE[noise_key]["rmse_8bit"])
+
+
+def _check_pixels_vs_reference(bgr, acc, ref_bgr, ref_cum, spp, floor):
     """Image bounds, each set from a measurement (tools/dbg/measure_parity.py on the MI355X, tests/golden/noise.json on the CPU):
     * the reference's non-finite pixels (inf/NaN surface colours of some Disney lobes times a black tail, renderer.c:69)
       are non-finite here and no others (measured: the sets are equal on every fixture);
@@ -193,12 +197,11 @@ def _check_frame_vs_reference(bgr, acc, g, spp, noise_key):
     * path-for-path agreement: a pixel's f32 sum agrees to 1e-4 relative unless one of its spp samples took another
       decision where a libm ulp decides (u2 <= F, reflectance > xi, the lobe interval): at most spp x 1e-4 of the
       pixels (measured per-sample rate 1e-5 to 5e-5 on every fixture)."""
-    assert np.array_equal(np.isfinite(g["cum"]).all(axis=2), np.isfinite(acc).all(axis=2))
-    fin = np.isfinite(g["cum"]).all(axis=2)
-    rmse = float(np.sqrt(np.mean((bgr[fin].astype(np.float64) - g["bgr"][fin].astype(np.float64)) ** 2)))
-    floor = NOISE[noise_key]["rmse_8bit"]
+    assert np.array_equal(np.isfinite(ref_cum).all(axis=-1), np.isfinite(acc).all(axis=-1))
+    fin = np.isfinite(ref_cum).all(axis=-1)
+    rmse = float(np.sqrt(np.mean((bgr[fin].astype(np.float64) - ref_bgr[fin].astype(np.float64)) ** 2)))
     assert rmse <= 1.1 * floor and rmse <= 0.01 * floor, (rmse, floor)
-    rel = np.abs(acc[fin] - g["cum"][fin]).max(axis=1) / np.maximum(np.abs(g["cum"][fin]).max(axis=1), 1e-3)
+    rel = np.abs(acc[fin] - ref_cum[fin]).max(axis=1) / np.maximum(np.abs(ref_cum[fin]).max(axis=1), 1e-3)
     assert (rel > 1e-4).mean() <= spp * 1e-4, float((rel > 1e-4).mean())
     return rmse
 
@@ -257,6 +260,49 @@ def test_config5_sample_range_split_vs_reference(built_scenes, device_scenes):
     assert np.array_equal(bgr1.cpu().numpy(), full_bgr)
 
 
+@pytest.mark.parametrize("name", ["sparse_bunny_1920x1080_64spp_d8", "sparse_dragon1_1920x1080_64spp_d8", "sparse_pear_1920x1080_64spp_d16"])
+def test_full_size_frames_vs_reference_pixels(built_scenes, device_scenes, name):
+    """BASELINE configs 2, 3 and 4 at their FULL size against the reference itself: the whole
+    1920x1080 x 64 spp frame is rendered by the default render loop — one slab of 132.7 M paths, binned queues, the
+    XCD-interleaved camera pass, the tail launch: everything that only engages at this size — and ~8 000 of its pixels
+    (a jittered grid + the silhouettes, contact lines and the light's rim) are held to the reference's own RenderPixel
+    sums for those pixels of that frame (ref_driver.c render_pixels; renderer.c:88-111) by the rules of
+    _check_frame_vs_reference, with the noise floor measured by the reference on exactly these pixels."""
+    g = golden(name + ".npz")
+    w, h, spp, depth, lo, hi = map(int, g["meta"])
+    scene = name.split("_")[1]
+    bgr, acc, st = device_scenes(scene).render(built_scenes(scene).rtx_camera(), hip.make_params(w, h, spp, depth, seed=(lo, hi)))
+    assert st["rays_at_depth"][0] == w * h * spp and st["passes"] == 1
+    pix = g["pix"].astype(np.int64)
+    rmse = _check_pixels_vs_reference(bgr.reshape(-1, 3)[pix], acc.reshape(-1, 3)[pix], g["bgr"], g["cum"], spp, float(g["noise_rmse_8bit"]))
+    print("%s: %d pixels, rmse %.4f (floor %.2f)" % (name, len(pix), rmse, float(g["noise_rmse_8bit"])))
+
+
+def test_config5_full_size_vs_reference_pixels(built_scenes, device_scenes):
+    """BASELINE config 5 at FULL size against the reference: 3840x2160, 1024 spp, depth 8, the eight sample shares
+    [128 r, 128 r + 128) rendered one after the other into ONE accumulation buffer (each continues the sequential
+    per-pixel sum of renderer.c:106, several slabs per share), and 1024 of the frame's pixels compared with the
+    reference's RenderPixel sums for those pixels of that frame."""
+    import torch
+    g = golden("sparse_dragon1_3840x2160_1024spp_d8.npz")
+    w, h, spp, depth, lo, hi = map(int, g["meta"])
+    assert (w, h, spp, depth) == (3840, 2160, 1024, 8)
+    sc, ds = built_scenes("dragon1"), device_scenes("dragon1")
+    cam, dev = sc.rtx_camera(), torch.device("cuda", 0)
+    buf = torch.zeros(h, w, 3, device=dev)
+    for r in range(8):
+        st = ds.render_device(cam, hip.make_params(w, h, spp, depth, seed=(lo, hi), sample_range=(128 * r, 128 * r + 128)), buf.data_ptr())
+        assert st["rays_at_depth"][0] == w * h * 128
+    bgr = torch.zeros(h, w, 3, dtype=torch.uint8, device=dev)
+    ds.resolve_device(buf.data_ptr(), w, h, spp, bgr.data_ptr())
+    torch.cuda.synchronize(dev)
+    pix = torch.from_numpy(g["pix"].astype(np.int64)).to(dev)
+    acc_p = buf.reshape(-1, 3)[pix].cpu().numpy()
+    bgr_p = bgr.reshape(-1, 3)[pix].cpu().numpy()
+    rmse = _check_pixels_vs_reference(bgr_p, acc_p, g["bgr"], g["cum"], spp, float(g["noise_rmse_8bit"]))
+    print("config 5 at full size: %d pixels, rmse %.4f (floor %.2f)" % (len(pix), rmse, float(g["noise_rmse_8bit"])))
+
+
 def test_config5_one_share_at_full_size(built_scenes, device_scenes):
     """BASELINE config 5 at full size, ONE rank's share: 3840x2160, samples [0, 128) of 1024, depth 8 (1.06 G camera
     paths in several slabs).  Properties that need no reference frame: one ray per camera path at depth 0, two runs
@@ -293,13 +339,19 @@ def test_depth_one_is_primary_visibility_only(built_scenes, device_scenes):
 
 
 def test_render_vs_oracle_larger_frame(built_scenes, device_scenes):
-    """Config-2 style frame (bunny, metal + Lambert ground) at 480x270, 16 spp, depth 8: GPU vs CPU oracle,
-    same seeds.  Ray counts per bounce agree to 0.1 %, the 8-bit images to >= 35 dB."""
+    """Config-2 style frame (bunny, metal + Lambert ground) at 480x270, 16 spp, depth 8: GPU vs CPU oracle, same seeds,
+    held to the rules of _check_frame_vs_reference (the bound is set from a measurement like the
+    others) — the noise floor is measured here, by the oracle against itself with another seed on this very frame.
+    Ray counts per bounce agree to 0.1 %."""
     sc, ds = built_scenes("bunny"), device_scenes("bunny")
     p = hip.make_params(480, 270, 16, 8, seed=(3, 4))
     bgr, acc, st = ds.render(sc.rtx_camera(), p)
     cum, obgr, rays = O.render(sc.desc, sc.rtx_camera(), p, threads=16)
-    assert psnr(bgr, obgr) >= 35.0
+    _, other, _ = O.render(sc.desc, sc.rtx_camera(), hip.make_params(480, 270, 16, 8, seed=(5, 6)), threads=16)
+    floor = float(np.sqrt(np.mean((obgr.astype(np.float64) - other.astype(np.float64)) ** 2)))
+    assert 5.0 < floor < 40.0, floor  # two correct renders with different streams (noise.json: 29.3 at 8 spp)
+    rmse = _check_pixels_vs_reference(bgr, acc, obgr, cum, 16, floor)
+    print("larger frame: rmse %.4f, floor %.2f, PSNR %.1f dB" % (rmse, floor, psnr(bgr, obgr)))
     for k, n in enumerate(st["rays_at_depth"]):
         assert abs(int(rays[k]) - n) <= max(4, 1e-3 * n), (k, int(rays[k]), n)
 

@@ -15,7 +15,7 @@ from oracle import binding as O
 from raytracer_amd import hip
 from util import GOLDEN, golden, same_bits
 
-SCENES = ["teapot", "bunny", "pear", "materials", "dragon1"]
+SCENES = ["teapot", "bunny", "pear", "materials", "dragon1", "teapotdof"]  # teapotdof: Camera_GetRay with a lens (camera.c:36-46)
 
 
 def test_rng_known_answer():
@@ -67,7 +67,8 @@ def test_camera_rays_bit_exact(built_scenes, scene):
 
 
 RENDERS = ["render_teapot_96x54_8spp_d8", "render_bunny_96x54_8spp_d8", "render_dragon1_96x54_8spp_d8",
-           "render_pear_96x54_8spp_d16", "render_materials_128x72_16spp_d8", "render_materials_64x36_4spp_d1"]
+           "render_pear_96x54_8spp_d16", "render_materials_128x72_16spp_d8", "render_materials_64x36_4spp_d1",
+           "render_teapotdof_96x54_8spp_d8"]
 
 
 @pytest.mark.parametrize("name", RENDERS)
@@ -79,6 +80,23 @@ def test_seeded_render_bit_exact(built_scenes, name):
     assert same_bits(cum, g["cum"])
     finite = np.isfinite(g["cum"]).all(axis=2)  # (u8)(NaN) is undefined in C: skip those pixels
     assert np.array_equal(bgr[finite], g["bgr"][finite])
+
+
+SPARSE = ["sparse_bunny_1920x1080_64spp_d8", "sparse_dragon1_1920x1080_64spp_d8", "sparse_pear_1920x1080_64spp_d16",
+          "sparse_dragon1_3840x2160_1024spp_d8"]
+
+
+@pytest.mark.parametrize("name", SPARSE)
+def test_full_size_pixels_bit_exact(built_scenes, name):
+    """BASELINE configs 2-5 at their FULL size (1080p x 64 spp; 4K x 1024 spp), a few thousand pixels each: the reference's
+    own RenderPixel sums for those pixels of the whole frame (ref_driver.c render_pixels — the per-path seeding makes a
+    pixel of the list the pixel of the frame) against the restatement's, bit for bit."""
+    g = golden(name + ".npz")
+    w, h, spp, depth, lo, hi = map(int, g["meta"])
+    sc = built_scenes(name.split("_")[1])
+    cum, rays = O.render_pixels(sc.desc, sc.rtx_camera(), hip.make_params(w, h, spp, depth, seed=(lo, hi)), g["pix"], threads=8)
+    assert same_bits(cum, g["cum"])
+    assert int(rays[0]) == len(g["pix"]) * spp
 
 
 def test_material_bounce_bit_exact(built_scenes):
