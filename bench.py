@@ -79,12 +79,16 @@ def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):
     try:
         rays, tried = rays_fn(w, h, spp, depth), []
         for t in variants:
-            kind = "perf_t%d" % t if O.ref_binary("perf_t%d" % t) else "perf"  # perf: the reference's own config.h, 16 threads
+            # 16 threads is the reference's own NUM_HYPERTHREADS (src/common/config.h:23): the stock build with the reference's
+            # own prelude (ref_perf) is the baseline there; ref_perf_t<N> (prelude_threads.h) only where N differs
+            kind = "perf_t%d" % t if t != 16 and O.ref_binary("perf_t%d" % t) else "perf"
             r = O.ref_run(kind, scenes.write_recipe(scene_name), assets.cache_dir(), "bench", w, h, spp, depth, timeout=900)
             tried.append({"threads": int(r["threads"]), "seconds": r["seconds"], "mrays_s": rays / r["seconds"] / 1e6})
         best = max(tried, key=lambda x: x["mrays_s"])
         out.update(value=best["mrays_s"], cores=best["threads"], seconds=best["seconds"], rays=rays, tried=tried, s_per_full_frame_extrapolated=None)
     except Exception as e:  # binary absent or cannot run on this host: fall back to the CPU port (oracle)
+        print("bench.py: cpu_baseline: the reference binary could not be timed (%s); timing the oracle port instead — kind \"port\""
+              % str(e)[:200], file=sys.stderr, flush=True)
         from raytracer_amd import hip
         sc = scenes.build(scene_name)
         p = hip.make_params(w, h, max(1, spp // 8), depth)
@@ -94,6 +98,50 @@ def cpu_baseline(scene_name, w, h, spp, depth, rays_fn):
         out.update(kind="port", cores=min(usable, 64), value=float(rays.sum()) / dt / 1e6, seconds=dt, rays=int(rays.sum()),
                    sample=out["sample"].replace("%d spp" % spp, "%d spp" % max(1, spp // 8)), note="ref_perf unavailable: %s" % str(e)[:120])
     return out
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the kernels: profiles/traffic.json carries the hash of the build its counters were
+    measured on (tools/profile_round.sh), and the counters are attached to a bench line only when it is this build's."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rt_hip.hip", "rtx_device.h", "kd_build.h"):
+        h.update(open(os.path.join(REPO, "raytracer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def in_process(args):
+    """--in-process N: the frame shared by N devices INSIDE librt_hip.so (rtx_render_multi: one host thread per device,
+    peer copies to device 0) — the path a C caller of include/rtx.h gets — timed beside the torch.distributed path.  With
+    fewer than N devices visible the handles wrap around the devices there are (a rehearsal, labelled)."""
+    import numpy as np
+    from raytracer_amd import hip, scenes
+    n = args.in_process
+    ndev = hip.device_count()
+    sc = scenes.build(args.scene)
+    cam = sc.rtx_camera()
+    dss = [hip.DeviceScene(sc.desc, r % ndev) for r in range(n)]
+    p = hip.make_params(args.width, args.height, args.spp, args.depth, seed=(1, 2))
+    split = hip.RTX_SPLIT_TILE if args.split == "tile" else hip.RTX_SPLIT_SAMPLE
+    for _ in range(args.warmup):
+        hip.render_multi(dss, cam, p, split, want_accum=False, want_bgr=False)
+    t0 = time.perf_counter()
+    sts = [hip.render_multi(dss, cam, p, split, want_accum=False, want_bgr=False)[2] for _ in range(args.steps)]
+    dt = time.perf_counter() - t0
+    rays = float(sum(s["rays_total"] for st in sts for s in st))
+    bgr, acc, _ = hip.render_multi(dss, cam, p, split)
+    _, whole, _ = dss[0].render(cam, p, want_bgr=False)
+    same = bool(np.array_equal(acc.view(np.uint32), whole.view(np.uint32))) if split == hip.RTX_SPLIT_TILE else bool(np.allclose(acc, whole, rtol=1e-5, atol=1e-5, equal_nan=True))
+    out = {"metric": "Mrays/s and s/frame, dragon.obj 1080p 64spp, at 1/2/4/8 MI355X", "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": n,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "s_per_frame": dt / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": same,
+           "config": {"workload": "%s %dx%d %d spp depth %d, %s split" % (args.scene, args.width, args.height, args.spp, args.depth, args.split),
+                      "driver": "rtx_render_multi (in-process, one host thread per device, peer copies to device 0)",
+                      "devices_visible": ndev, "rehearsal_on_fewer_devices": ndev < n,
+                      "slowest_device_ms": max(s["ms_total"] for s in sts[-1])}}
+    print(json.dumps(out), flush=True)
+    for ds in dss:
+        ds.close()
 
 
 def main():
@@ -109,8 +157,12 @@ def main():
     ap.add_argument("--split", default="tile", choices=["tile", "sample"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="after timing: the reduced frame against a single-rank render of the same frame")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1 verifies by default")
+    ap.add_argument("--in-process", type=int, default=0, metavar="N", help="share the frame among N devices inside librt_hip.so (rtx_render_multi) instead of one rank per GPU")
     ap.add_argument("--save-bmp", default="")
     args = ap.parse_args()
+    if args.in_process > 0:
+        return in_process(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,7 +227,7 @@ def main():
     dt = time.perf_counter() - t0
 
     verified = None
-    if args.verify:
+    if args.verify or (world > 1 and not args.no_verify):  # N > 1: always, so that a scaling line carries "verified"
         # The frame the ranks just produced together against the whole frame rendered by rank 0 alone.  Tile split: every
         # pixel is written by exactly one rank and the reduce adds zeros to it, so the two buffers are equal BIT FOR BIT;
         # sample split: the same terms in another f32 association (rtol 1e-5).  At N = 1 the check is the partition
@@ -235,12 +287,18 @@ def main():
         tj = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tj):  # measured in a separate rocprofv3 --pmc run of this same command (profiles/)
             tr = json.load(open(tj))
-            if tr.get("workload") == "%s %dx%d %dspp d%d" % (args.scene, args.width, args.height, args.spp, args.depth) and world == 1:
+            stale = tr.get("kernel_source_hash") != kernel_source_hash()
+            if stale:
+                print("bench.py: profiles/traffic.json was measured on another build of the kernels (%s, hash %s; this build %s): "
+                      "roofline.traffic and roofline.counters left out" % (tr.get("measured_at"), tr.get("kernel_source_hash"), kernel_source_hash()),
+                      file=sys.stderr, flush=True)
+            if not stale and tr.get("workload") == "%s %dx%d %dspp d%d" % (args.scene, args.width, args.height, args.spp, args.depth) and world == 1:
                 traffic = tr.get("hbm_bytes_per_launch")
                 counters = {k: tr[k] for k in ("hbm_gbs", "l2_hit_rate", "valu_busy", "valu_lane_utilisation", "valu_insts_per_traced_ray") if tr.get(k) is not None}
                 # NOT measured in this run: copied from the rocprofv3 --pmc passes of this same command kept in profiles/
                 counters["source"] = "profiles/traffic.json (separate rocprofv3 --pmc runs of this command, tools/profile_round.sh)"
                 counters["measured_at"] = tr.get("measured_at", "round 1, kernel v18")
+                counters["kernel_source_hash"] = tr.get("kernel_source_hash")
         out = {
             "metric": "Mrays/s and s/frame, dragon.obj 1080p 64spp, at 1/2/4/8 MI355X",
             "value": rays_total / t / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -193,6 +193,10 @@ bool       Render_Done(RenderCtx* ctx);                                         
  * the status of the last finished render (RTX_OK or RTX_E_*), and its stats. */
 void Render_Set_Seed(RenderCtx* ctx, uint64_t seed_lo, uint64_t seed_hi);
 void Render_Set_Device(RenderCtx* ctx, int device);
+/* The next Render_Start shares its frame among n devices the way Render_Waiter shares it among NUM_HYPERTHREADS workers
+ * (src/rt/renderer.c:186-237): rtx_render_multi with split_mode RTX_SPLIT_TILE (interleaved bands of band_rows rows,
+ * 0 = 8; BASELINE config 3) or RTX_SPLIT_SAMPLE (config 5).  false (and no change) for n = 0 or n > 64. */
+bool Render_Set_Devices(RenderCtx* ctx, const int* devices, uint32_t n, uint32_t split_mode, uint32_t band_rows);
 /* Progressive frame for the next Render_Start (main.c:436-478 polls and blits ctx->img->pix every
  * 200 ms while the workers fill it in): spp_per_pass > 0 makes the image fill in by passes of that many samples
  * (rtx_render_progressive); a frame that runs to the end is byte-identical to the all-at-once frame.

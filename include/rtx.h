@@ -197,7 +197,8 @@ int         rtx_device_count(int* count);
  * bits; none changes a result) live in one process-wide table: OVERLAP, SORT_DEPTH, SORT_MIN, SORT_EVERY, TAIL_MAX,
  * TAIL_SHADE_MIN, JUMP_TABLE, RAYGEN_LEAN, EARLY_MISS, FAST_DIV, BAND_TILES, TRACE_CHUNK, AHEAD, TILE_INTERLEAVE.  The environment
  * (RTX_<NAME>) is read ONCE, at first use, for the defaults; no entry point reads the environment per call.  Set a knob
- * only while no call is in flight.  No counterpart in the reference (its switches are compile-time, src/common/config.h). ---- */
+ * only while no call is in flight; a value outside a knob's range is RTX_E_INVALID (TRACE_CHUNK 0..4096, OVERLAP 0..3,
+ * TAIL_SHADE_MIN 1..64, the on/off knobs 0..1), and so is any change while rtx_render_multi runs.  No counterpart in the reference (its switches are compile-time, src/common/config.h). ---- */
 int  rtx_tune_set(const char* name, long long value);
 int  rtx_tune_get(const char* name, long long* value);
 void rtx_tune_reset(void); /* back to the defaults (built-in, or RTX_<NAME> as it was at first use) */
@@ -279,6 +280,25 @@ int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params*
 typedef int (*rtx_progress_fn)(void* user, uint32_t samples_done, uint32_t samples_total);
 int rtx_render_progressive(rtx_scene* scene, const rtx_camera* cam, const rtx_render_params* params, uint32_t spp_per_pass,
                            uint8_t* bgr_out, float* accum_out, rtx_progress_fn progress, void* user, rtx_stats* stats);
+
+/* ---- one frame over SEVERAL devices: what Render_Waiter does with its NUM_HYPERTHREADS workers (src/rt/renderer.c:186-237:
+ *      spawn one worker per hardware thread, let them share the frame, join) with one host thread per DEVICE.  scenes[r] is
+ *      the scene uploaded to device r of the job (rtx_scene_create of the same description on n devices; handles on the
+ *      same device are allowed and serialise there).  `params` describes the WHOLE frame (band_* and sample_* must be 0).
+ *        RTX_SPLIT_TILE:   device r renders the bands b = r (mod n) of `band_rows` rows (0 = 8) — BASELINE config 3; the
+ *                          shares are disjoint and are copied into scenes[0]'s buffer device to device: bgr_out / accum_out
+ *                          are rtx_render's, bit for bit;
+ *        RTX_SPLIT_SAMPLE: device r renders samples [r spp/n, (r+1) spp/n) of every pixel — config 5; the shares are added
+ *                          on scenes[0]'s device in rank order (partial sums of renderer.c:106 in another association:
+ *                          equal to rtx_render's sums to f32 rounding, reproducible from run to run).
+ *      The shares travel by hipMemcpyPeerAsync over xGMI (n-1 peers, n-1 links into the root); no communicator, no
+ *      library beyond the HIP runtime.  Blocking.  bgr_out / accum_out: host, as in rtx_render, may be NULL (the call
+ *      then only renders and reduces: what a benchmark times).  stats: n entries (one per device) or NULL.
+ *      The tuning table is read-only while a call runs (rtx_tune_set fails). ---- */
+#define RTX_SPLIT_TILE   0u
+#define RTX_SPLIT_SAMPLE 1u
+int rtx_render_multi(rtx_scene* const* scenes, uint32_t n_scenes, const rtx_camera* cam, const rtx_render_params* params,
+                     uint32_t split_mode, uint32_t band_rows, uint8_t* bgr_out, float* accum_out, rtx_stats* stats);
 
 /* Device-output variant for multi-GPU: d_accum (f32 x 3 x W x H, device) receives the per-pixel
  * sums of the rows/samples assigned to this call, ADDED sample by sample, in sample order, to what the buffer

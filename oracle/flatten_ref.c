@@ -236,6 +236,7 @@ typedef struct {
     int (*scene_create)(const rtx_scene_desc*, int, rtx_scene**);
     int (*scene_destroy)(rtx_scene*);
     int (*render)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint8_t*, float*, rtx_stats*);
+    int (*render_multi)(rtx_scene* const*, uint32_t, const rtx_camera*, const rtx_render_params*, uint32_t, uint32_t, uint8_t*, float*, rtx_stats*);
     const char* (*last_error)(void);
 } RtxLib;
 
@@ -249,9 +250,10 @@ static RtxLib* rtx_lib(void)
     lib.scene_create  = (int (*)(const rtx_scene_desc*, int, rtx_scene**))dlsym(h, "rtx_scene_create");
     lib.scene_destroy = (int (*)(rtx_scene*))dlsym(h, "rtx_scene_destroy");
     lib.render        = (int (*)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint8_t*, float*, rtx_stats*))dlsym(h, "rtx_render");
+    lib.render_multi  = (int (*)(rtx_scene* const*, uint32_t, const rtx_camera*, const rtx_render_params*, uint32_t, uint32_t, uint8_t*, float*, rtx_stats*))dlsym(h, "rtx_render_multi");
     lib.last_error    = (const char* (*)(void))dlsym(h, "rtx_last_error");
     int (*abi)(void)  = (int (*)(void))dlsym(h, "rtx_abi_version");
-    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.last_error || !abi) ABORT("Render_Start_HIP: librt_hip.so lacks the rtx_* entry points");
+    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.render_multi || !lib.last_error || !abi) ABORT("Render_Start_HIP: librt_hip.so lacks the rtx_* entry points");
     if (abi() != RTX_ABI_VERSION) ABORT("Render_Start_HIP: librt_hip.so has ABI %d, this binding %d", abi(), RTX_ABI_VERSION);
     lib.handle = h;
     return &lib;
@@ -271,6 +273,30 @@ static u64 seed_word(const char* env_name) // RTX_SEED_LO / RTX_SEED_HI pin the 
     return v;
 }
 
+#define RTX_MAX_DEVICES 64
+
+// RTX_DEVICES="0,1,2,3,4,5,6,7" (default: RTX_DEVICE, default 0): the devices that share the frame — where Render_Waiter
+// sizes its worker array by NUM_HYPERTHREADS (renderer.c:208-209)
+static uint32_t device_list(int* ids)
+{
+    const char* list = getenv("RTX_DEVICES");
+    uint32_t    n    = 0;
+    if (list && *list) {
+        for (const char* p = list; *p && n < RTX_MAX_DEVICES;) {
+            char* end;
+            long  v = strtol(p, &end, 10);
+            if (end == p || v < 0) ABORT("RTX_DEVICES: cannot read '%s'", list);
+            ids[n++] = (int)v;
+            p        = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') ABORT("RTX_DEVICES: cannot read '%s'", list);
+        }
+    } else {
+        const char* one = getenv("RTX_DEVICE");
+        ids[n++]        = one ? atoi(one) : 0;
+    }
+    return n;
+}
+
 static void Render_Waiter_HIP(void* arg) // stands where Render_Waiter + Render_Worker stand (renderer.c:141-237)
 {
     HipWaiterArg* a   = (HipWaiterArg*)arg;
@@ -278,17 +304,30 @@ static void Render_Waiter_HIP(void* arg) // stands where Render_Waiter + Render_
     RtxLib*       lib = rtx_lib();
     RtxFlat*      flat = Rtx_Flatten(ctx->scene);
     if (!flat) ABORT("Render_Start_HIP: the scene cannot be flattened");
-    rtx_scene*  dev    = NULL;
-    const char* dev_no = getenv("RTX_DEVICE");
-    if (lib->scene_create(&flat->desc, dev_no ? atoi(dev_no) : 0, &dev) != RTX_OK) ABORT("rtx_scene_create: %s", lib->last_error()); // the reference aborts on any failure (macros.h:60-64)
+    int        ids[RTX_MAX_DEVICES];
+    rtx_scene* dev[RTX_MAX_DEVICES];
+    uint32_t   n = device_list(ids);
+    for (uint32_t i = 0; i < n; i++) // the scene is replicated: every device holds the whole tree (the reference's workers share one)
+        if (lib->scene_create(&flat->desc, ids[i], &dev[i]) != RTX_OK) ABORT("rtx_scene_create on device %d: %s", ids[i], lib->last_error()); // the reference aborts on any failure (macros.h:60-64)
     rtx_render_params p;
     memset(&p, 0, sizeof p);
     p.width = (uint32_t)ctx->img->res.width, p.height = (uint32_t)ctx->img->res.height;
     p.spp = (uint32_t)a->samples_per_pixel, p.max_depth = (uint32_t)a->max_ray_depth;
     p.seed_lo = seed_word("RTX_SEED_LO"), p.seed_hi = seed_word("RTX_SEED_HI");
     // ImageRGB.pix is RGB{b,g,r} (color.h:19-23), row 0 = bottom scanline: exactly rtx_render's bgr_out; Camera is rtx_camera
-    if (lib->render(dev, (const rtx_camera*)ctx->cam, &p, (uint8_t*)ctx->img->pix, NULL, NULL) != RTX_OK) ABORT("rtx_render: %s", lib->last_error());
-    lib->scene_destroy(dev);
+    if (n == 1) {
+        if (lib->render(dev[0], (const rtx_camera*)ctx->cam, &p, (uint8_t*)ctx->img->pix, NULL, NULL) != RTX_OK) ABORT("rtx_render: %s", lib->last_error());
+    } else {
+        // RTX_SPLIT=sample: every device traces its range of the samples of every pixel (BASELINE config 5); default: tile
+        // split, interleaved bands of RTX_BAND_ROWS rows (config 3).  One worker per device inside the library, joined there.
+        const char* split = getenv("RTX_SPLIT");
+        const char* rows  = getenv("RTX_BAND_ROWS");
+        if (lib->render_multi(dev, n, (const rtx_camera*)ctx->cam, &p, split && !strcmp(split, "sample") ? RTX_SPLIT_SAMPLE : RTX_SPLIT_TILE,
+                              rows ? (uint32_t)atoi(rows) : 0u, (uint8_t*)ctx->img->pix, NULL, NULL)
+            != RTX_OK)
+            ABORT("rtx_render_multi: %s", lib->last_error());
+    }
+    for (uint32_t i = 0; i < n; i++) lib->scene_destroy(dev[i]);
     Rtx_FlatDelete(flat);
     ctx->finished = true; // renderer.c:236
 }

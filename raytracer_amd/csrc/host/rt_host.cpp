@@ -1724,6 +1724,7 @@ struct HipLib {
     int (*scene_destroy)(rtx_scene*);
     int (*render)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint8_t*, float*, rtx_stats*);
     int (*render_progressive)(rtx_scene*, const rtx_camera*, const rtx_render_params*, uint32_t, uint8_t*, float*, rtx_progress_fn, void*, rtx_stats*);
+    int (*render_multi)(rtx_scene* const*, uint32_t, const rtx_camera*, const rtx_render_params*, uint32_t, uint32_t, uint8_t*, float*, rtx_stats*);
     const char* (*last_error)(void);
 };
 
@@ -1756,7 +1757,8 @@ static HipLib* load_hip_lib()
     lib.render        = (decltype(lib.render))dlsym(h, "rtx_render");
     lib.last_error    = (decltype(lib.last_error))dlsym(h, "rtx_last_error");
     lib.render_progressive = (decltype(lib.render_progressive))dlsym(h, "rtx_render_progressive");
-    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.render_progressive || !lib.last_error) {
+    lib.render_multi       = (decltype(lib.render_multi))dlsym(h, "rtx_render_multi");
+    if (!lib.scene_create || !lib.scene_destroy || !lib.render || !lib.render_progressive || !lib.render_multi || !lib.last_error) {
         set_err("Render_Start: %s lacks the rtx_* entry points", path.c_str());
         dlclose(h);
         return NULL;
@@ -1770,6 +1772,8 @@ struct WaiterArgs {
     size_t     samples_per_pixel, max_ray_depth;
     uint64_t   seed_lo, seed_hi;
     int        device;
+    int        devices[64]; // Render_Set_Devices: the devices that share the frame (n_devices > 1: rtx_render_multi)
+    uint32_t   n_devices, split_mode, band_rows;
     uint32_t   spp_per_pass; // 0: the frame appears at once; else it fills in by passes of that many samples
     volatile int stop;       // Render_Stop: end the frame after the pass in flight
     volatile uint32_t samples_done;
@@ -1825,7 +1829,24 @@ extern "C" void Render_Set_Seed(RenderCtx* ctx, uint64_t lo, uint64_t hi)
     wa->seed_hi    = hi;
 }
 
-extern "C" void Render_Set_Device(RenderCtx* ctx, int device) { ((WaiterArgs*)ctx->waiter_args)->device = device; }
+extern "C" void Render_Set_Device(RenderCtx* ctx, int device)
+{
+    WaiterArgs* wa = (WaiterArgs*)ctx->waiter_args;
+    wa->device     = device;
+    wa->n_devices  = 0;
+}
+
+// The frame of the next Render_Start is shared by n devices, as Render_Waiter shares it among NUM_HYPERTHREADS workers
+// (renderer.c:186-237): split_mode RTX_SPLIT_TILE (interleaved bands of band_rows rows, 0 = 8) or RTX_SPLIT_SAMPLE.
+// Ignored (false) for n > 64; a progressive frame (Render_Set_Progressive) stays on devices[0].
+extern "C" bool Render_Set_Devices(RenderCtx* ctx, const int* devices, uint32_t n, uint32_t split_mode, uint32_t band_rows)
+{
+    WaiterArgs* wa = (WaiterArgs*)ctx->waiter_args;
+    if (!devices || n == 0 || n > 64) return false;
+    memcpy(wa->devices, devices, n * sizeof(int));
+    wa->device = devices[0], wa->n_devices = n, wa->split_mode = split_mode, wa->band_rows = band_rows;
+    return true;
+}
 
 // The reference's image fills in tile by tile while main.c blits it every 200 ms (main.c:436-478); here it
 // fills in by samples: after every pass of `spp_per_pass` samples ctx->img->pix holds the image so far.
@@ -1867,6 +1888,39 @@ static void* Render_Waiter(void* arg) // stands in for Render_Waiter + Render_Wo
     flat = Scene_Flatten(ctx->scene);
     if (!flat) {
         snprintf(wa->err, sizeof wa->err, "%s", g_err);
+        goto done;
+    }
+    if (wa->n_devices > 1 && !wa->spp_per_pass) { // one frame over several devices: the library runs one worker per device
+        rtx_scene* devs[64] = {NULL};
+        uint32_t   made     = 0;
+        wa->status          = RTX_OK;
+        for (; made < wa->n_devices && wa->status == RTX_OK; made++) wa->status = lib->scene_create(&flat->desc, wa->devices[made], &devs[made]);
+        if (wa->status != RTX_OK) {
+            snprintf(wa->err, sizeof wa->err, "%s", lib->last_error());
+            made--; // the last one was not created
+        } else {
+            rtx_render_params p;
+            memset(&p, 0, sizeof p);
+            p.width = (uint32_t)ctx->img->res.width, p.height = (uint32_t)ctx->img->res.height;
+            p.spp = (uint32_t)wa->samples_per_pixel, p.max_depth = (uint32_t)wa->max_ray_depth;
+            p.seed_lo = wa->seed_lo, p.seed_hi = wa->seed_hi;
+            std::vector<rtx_stats> st(wa->n_devices);
+            wa->status = lib->render_multi(devs, wa->n_devices, (const rtx_camera*)ctx->cam, &p, wa->split_mode, wa->band_rows, (uint8_t*)ctx->img->pix, NULL, st.data());
+            if (wa->status != RTX_OK) snprintf(wa->err, sizeof wa->err, "%s", lib->last_error());
+            else { // the job's stats: counts summed over the devices, times of the slowest
+                wa->stats = st[0];
+                for (uint32_t r = 1; r < wa->n_devices; r++) {
+                    wa->stats.rays_total += st[r].rays_total, wa->stats.camera_paths += st[r].camera_paths, wa->stats.hits_shaded += st[r].hits_shaded;
+                    wa->stats.rays_early_miss += st[r].rays_early_miss, wa->stats.trace_launches += st[r].trace_launches, wa->stats.passes += st[r].passes;
+                    for (int k = 0; k < RTX_MAX_DEPTH; k++) wa->stats.rays_at_depth[k] += st[r].rays_at_depth[k];
+                    wa->stats.ms_total = std::max(wa->stats.ms_total, st[r].ms_total), wa->stats.ms_trace = std::max(wa->stats.ms_trace, st[r].ms_trace);
+                    wa->stats.ms_shade = std::max(wa->stats.ms_shade, st[r].ms_shade);
+                }
+                wa->stats.samples_done = p.spp;
+                wa->samples_done       = p.spp;
+            }
+        }
+        for (uint32_t r = 0; r < made; r++) lib->scene_destroy(devs[r]);
         goto done;
     }
     wa->status = lib->scene_create(&flat->desc, wa->device, &dev);

@@ -21,6 +21,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -75,23 +76,25 @@ enum { K_OVERLAP, K_SORT_DEPTH, K_SORT_MIN, K_SORT_EVERY, K_TAIL_MAX, K_TAIL_SHA
 struct Knob {
     const char* name;
     long long   dflt, value;
+    long long   lo, hi; // accepted range (rtx_tune_set refuses the rest: several knobs reach kernels as 32-bit launch arguments)
 };
 static Knob g_knobs[K_COUNT] = {
-    {"OVERLAP", 0, 0},            // 1..3: the assigned pixels go through the bounce loop as 2..4 parts on as many streams
-    {"SORT_DEPTH", 2, 0},         // bin the queues that feed depth >= this; 0 = never
-    {"SORT_MIN", 1500000, 0},     // ... if they hold at least this many rays
-    {"SORT_EVERY", 1, 0},         // ... every k-th eligible depth
-    {"TAIL_MAX", TAIL_MAX_DEFAULT, 0}, // longest queue handed to the tail launch; 0 = never
-    {"TAIL_SHADE_MIN", 16, 0},    // lanes that wait before the tail launch shades in place
-    {"JUMP_TABLE", 1, 0},         // 0: the literal 128-step seed jump in raygen
-    {"RAYGEN_LEAN", 1, 0},        // 0: raygen stores whole path records
-    {"EARLY_MISS", 1, 0},         // 0: every bounce ray goes through the closest-hit kernel
-    {"FAST_DIV", 1, 0},           // 0: plain divisions in the index decode
-    {"BAND_TILES", 1, 0},         // 0: 32 x 32 path tiles under the band split too
-    {"TRACE_CHUNK", 0, 0},        // rays per work grab of the closest-hit kernel; 0 = by queue length
-    {"AHEAD", 1, 0},              // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
-    {"TILE_INTERLEAVE", 4096, 0}, // camera pass: the queue's eight parts (one per XCD) are runs of this many rays dealt out in turn; 0: its eighths
+    {"OVERLAP", 0, 0, 0, 3},                  // 1..3: the assigned pixels go through the bounce loop as 2..4 parts on as many streams
+    {"SORT_DEPTH", 2, 0, 0, RTX_MAX_DEPTH},   // bin the queues that feed depth >= this; 0 = never
+    {"SORT_MIN", 1500000, 0, 0, 1ll << 40},   // ... if they hold at least this many rays
+    {"SORT_EVERY", 1, 0, 1, 1ll << 20},       // ... every k-th eligible depth
+    {"TAIL_MAX", TAIL_MAX_DEFAULT, 0, 0, 1ll << 40}, // longest queue handed to the tail launch; 0 = never
+    {"TAIL_SHADE_MIN", 16, 0, 1, 64},         // lanes that wait before the tail launch shades in place
+    {"JUMP_TABLE", 1, 0, 0, 1},               // 0: the literal 128-step seed jump in raygen
+    {"RAYGEN_LEAN", 1, 0, 0, 1},              // 0: raygen stores whole path records
+    {"EARLY_MISS", 1, 0, 0, 1},               // 0: every bounce ray goes through the closest-hit kernel
+    {"FAST_DIV", 1, 0, 0, 1},                 // 0: plain divisions in the index decode
+    {"BAND_TILES", 1, 0, 0, 1},               // 0: 32 x 32 path tiles under the band split too
+    {"TRACE_CHUNK", 0, 0, 0, 4096},           // rays per work grab of the closest-hit kernel (16 at least); 0 = by queue length
+    {"AHEAD", 1, 0, 0, 1},                    // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
+    {"TILE_INTERLEAVE", 4096, 0, 0, 1ll << 40}, // camera pass: the queue's eight parts (one per XCD) are runs of this many rays dealt out in turn; 0: its eighths
 };
+static std::atomic<int> g_multi_in_flight{0}; // rtx_render_multi calls running: the table is read-only meanwhile
 static std::once_flag g_knobs_once;
 static void knobs_init()
 {
@@ -100,7 +103,11 @@ static void knobs_init()
             char env[64];
             snprintf(env, sizeof env, "RTX_%s", k.name);
             const char* e = getenv(env);
-            k.dflt  = e ? atoll(e) : k.dflt; // the environment at load time sets the default
+            if (e) { // the environment at load time sets the default (out of range: the built-in default stands, loudly)
+                const long long v = atoll(e);
+                if (v >= k.lo && v <= k.hi) k.dflt = v;
+                else fprintf(stderr, "librt_hip: %s=%s is outside [%lld, %lld]; ignored\n", env, e, k.lo, k.hi);
+            }
             k.value = k.dflt;
         }
     });
@@ -122,6 +129,8 @@ extern "C" int rtx_tune_set(const char* name, long long value)
 {
     Knob* k = find_knob(name);
     if (!k) return fail(RTX_E_INVALID, "unknown tuning knob '%s'", name ? name : "(null)");
+    if (value < k->lo || value > k->hi) return fail(RTX_E_INVALID, "tuning knob %s = %lld is outside [%lld, %lld]", k->name, value, k->lo, k->hi);
+    if (g_multi_in_flight.load() != 0) return fail(RTX_E_INVALID, "tuning knobs are read-only while rtx_render_multi runs");
     k->value = value;
     return RTX_OK;
 }
@@ -135,6 +144,7 @@ extern "C" int rtx_tune_get(const char* name, long long* value)
 extern "C" void rtx_tune_reset(void)
 {
     knobs_init();
+    if (g_multi_in_flight.load() != 0) return; // read-only while rtx_render_multi runs
     for (Knob& k : g_knobs) k.value = k.dflt;
 }
 
@@ -175,6 +185,9 @@ struct rtx_scene {
     hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
     unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
+    void*    multi_buf[2];   // rtx_render_multi: this scene's share of the frame (f32 x 3 x W x H) and, on the root, the staging of the peers' shares
+    uint64_t multi_bytes[2];
+    hipStream_t multi_stream;
     unsigned char* noalloc_scratch; // this device's copy of the static scratch array of rtx_closest_hit_noalloc (hipGetSymbolAddress, at create)
     unsigned persist_blocks[10]; // resident grid of the persistent kernels: [count + 2 * (variant - 2)], [8 + variant - 4]: tail (0 = not queried yet)
 };
@@ -230,6 +243,9 @@ extern "C" int rtx_scene_destroy(rtx_scene* sc)
     (void)hipSetDevice(sc->device);
     for (void* p : sc->allocs) (void)hipFree(p);
     if (sc->ws) (void)hipFree(sc->ws);
+    for (void* b : sc->multi_buf)
+        if (b) (void)hipFree(b);
+    if (sc->multi_stream) (void)hipStreamDestroy(sc->multi_stream);
     for (int i = 0; i < sc->n_ev; i++) (void)hipEventDestroy(sc->ev[i]);
     for (int i = 0; i < RTX_MAX_LANES - 1; i++) {
         if (sc->aux_stream[i]) (void)hipStreamDestroy(sc->aux_stream[i]);
@@ -3218,6 +3234,160 @@ extern "C" int rtx_render_progressive(rtx_scene* sc, const rtx_camera* cam, cons
 {
     if (spp_per_pass == 0) return fail(RTX_E_INVALID, "rtx_render_progressive: spp_per_pass must be positive");
     return render_host(sc, cam, p, spp_per_pass, bgr_out, accum_out, progress, user, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One frame over several devices behind the C ABI.
+//
+// The reference's Render_Waiter spawns NUM_HYPERTHREADS workers that share the frame and joins them
+// (src/rt/renderer.c:186-237); here the waiter's workers are one host thread per DEVICE: each renders its share — the
+// interleaved bands b = r (mod n) of `band_rows` rows, or the samples [r spp/n, (r+1) spp/n) of every pixel — with its own
+// replicated scene into a full-frame f32 buffer on its device, and the shares meet on the root (scenes[0]'s device):
+//   * tile split: the bands are disjoint, so a share's rows are COPIED into the root's buffer, band by band, device to device
+//     (hipMemcpyPeerAsync; 1/n of the frame per peer): the frame is rtx_render's bit for bit;
+//   * sample split: a peer's buffer is copied whole into a staging buffer on the root and ADDED there in rank order
+//     (k_accum_add): partial sums of the per-pixel sum of renderer.c:106 in another association, as any reduce gives.
+// Why peer copies and not RCCL here: it is ONE reduction to ONE root of 25-100 MB per frame, inside one process.  On the
+// xGMI mesh the n-1 peers write over n-1 different links into the root at the same time (0.16-0.65 ms), the sum
+// order is fixed (rank order: reproducible frames), nothing needs a communicator (ncclCommInitAll takes seconds and pulls
+// a gigabyte library into a C renderer) and a C caller links nothing but libamdhip64.  The multi-PROCESS path
+// (bench.py under torch.distributed.run, raytracer_amd/distributed.py) is the one that reduces through RCCL.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_accum_add(float* __restrict__ acc, const float* __restrict__ part, uint64_t n4, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        float4 a = ((float4*)acc)[i];
+        const float4 b = ((const float4*)part)[i];
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        ((float4*)acc)[i] = a;
+    } else if (i == n4) {
+        for (uint64_t k = 4 * n4; k < n; k++) acc[k] += part[k];
+    }
+}
+
+static int multi_buffer(rtx_scene* sc, int which, uint64_t bytes, float** out) // device current
+{
+    if (sc->multi_bytes[which] < bytes) {
+        if (sc->multi_buf[which]) (void)hipFree(sc->multi_buf[which]);
+        sc->multi_buf[which]   = nullptr;
+        sc->multi_bytes[which] = 0;
+        hipError_t e = hipMalloc(&sc->multi_buf[which], bytes);
+        if (e != hipSuccess) return fail(RTX_E_NOMEM, "rtx_render_multi: cannot allocate %llu bytes on device %d: %s", (unsigned long long)bytes, sc->device, hipGetErrorString(e));
+        sc->multi_bytes[which] = bytes;
+    }
+    *out = (float*)sc->multi_buf[which];
+    return RTX_OK;
+}
+
+struct MultiWorker {
+    rtx_scene*        sc;
+    rtx_render_params p;
+    float*            d_share;
+    rtx_stats         st;
+    int               rc;
+    char              err[sizeof g_err];
+};
+
+extern "C" int rtx_render_multi(rtx_scene* const* scenes, uint32_t n, const rtx_camera* cam, const rtx_render_params* params, uint32_t split_mode,
+                                uint32_t band_rows, uint8_t* bgr_out, float* accum_out, rtx_stats* stats)
+{
+    if (!scenes || n == 0 || !cam || !params) return fail(RTX_E_INVALID, "rtx_render_multi: null argument");
+    if (n > 64) return fail(RTX_E_LIMIT, "rtx_render_multi: at most 64 scene handles");
+    if (split_mode != RTX_SPLIT_TILE && split_mode != RTX_SPLIT_SAMPLE) return fail(RTX_E_INVALID, "rtx_render_multi: split_mode must be RTX_SPLIT_TILE or RTX_SPLIT_SAMPLE");
+    for (uint32_t r = 0; r < n; r++) {
+        if (!scenes[r]) return fail(RTX_E_INVALID, "rtx_render_multi: scene handle %u is null", r);
+        for (uint32_t q = 0; q < r; q++)
+            if (scenes[q] == scenes[r]) return fail(RTX_E_INVALID, "rtx_render_multi: scene handle %u is handle %u again (a handle serves one call at a time)", r, q);
+    }
+    if (params->band_rows || params->band_rank || params->band_world || params->sample_begin || params->sample_end)
+        return fail(RTX_E_INVALID, "rtx_render_multi: params describes the WHOLE frame (band_* and sample_* must be 0; the call derives the shares)");
+    FrameGeom g;
+    uint32_t  rows = 0;
+    int       rc   = check_params(params, &g, &rows);
+    if (rc != RTX_OK) return rc;
+    if (split_mode == RTX_SPLIT_TILE && band_rows == 0) band_rows = 8; // 8-row bands balance best at N = 8
+    if (split_mode == RTX_SPLIT_SAMPLE && params->spp < n) return fail(RTX_E_INVALID, "rtx_render_multi: sample split of %u samples over %u devices", params->spp, n);
+    const uint64_t npx = (uint64_t)params->width * params->height, fbytes = npx * 12;
+    rtx_scene*     root = scenes[0];
+
+    struct InFlight { InFlight() { g_multi_in_flight++; } ~InFlight() { g_multi_in_flight--; } } in_flight; // the tuning table is read-only from here on
+    knobs_init();
+
+    std::vector<MultiWorker> w(n);
+    for (uint32_t r = 0; r < n; r++) {
+        w[r].sc = scenes[r], w[r].p = *params, w[r].rc = RTX_OK, w[r].err[0] = 0, w[r].d_share = nullptr;
+        memset(&w[r].st, 0, sizeof w[r].st);
+        if (split_mode == RTX_SPLIT_TILE) w[r].p.band_rows = band_rows, w[r].p.band_rank = r, w[r].p.band_world = n;
+        else w[r].p.sample_begin = (uint32_t)((uint64_t)r * params->spp / n), w[r].p.sample_end = (uint32_t)((uint64_t)(r + 1) * params->spp / n);
+    }
+    // one worker per device (renderer.c:205-233: spawn, then join)
+    auto work = [&](uint32_t r) {
+        MultiWorker& m = w[r];
+        auto body = [&]() -> int {
+            HIPCHECK(hipSetDevice(m.sc->device));
+            if (!m.sc->multi_stream) HIPCHECK(hipStreamCreateWithFlags(&m.sc->multi_stream, hipStreamNonBlocking));
+            int rc2 = multi_buffer(m.sc, 0, fbytes, &m.d_share);
+            if (rc2 != RTX_OK) return rc2;
+            // a one-device tile "split" renders the whole frame; any other share starts from zeros (rows / samples of the
+            // others stay zero: the sample split adds whole buffers)
+            HIPCHECK(hipMemsetAsync(m.d_share, 0, fbytes, m.sc->multi_stream));
+            rc2 = rtx_render_device(m.sc, cam, &m.p, m.d_share, m.sc->multi_stream, &m.st); // synchronises its stream
+            return rc2;
+        };
+        m.rc = body();
+        if (m.rc != RTX_OK) memcpy(m.err, g_err, sizeof m.err);
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t r = 1; r < n; r++) th.emplace_back(work, r);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (uint32_t r = 0; r < n; r++)
+        if (w[r].rc != RTX_OK) {
+            memcpy(g_err, w[r].err, sizeof g_err);
+            return w[r].rc;
+        }
+    if (stats)
+        for (uint32_t r = 0; r < n; r++) stats[r] = w[r].st;
+
+    // the shares meet on the root
+    HIPCHECK(hipSetDevice(root->device));
+    hipStream_t rs = root->multi_stream;
+    float*      d_frame = w[0].d_share;
+    auto peer_copy = [&](void* dst, const void* src, int src_dev, uint64_t bytes) -> hipError_t {
+        return src_dev == root->device ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rs)
+                                       : hipMemcpyPeerAsync(dst, root->device, src, src_dev, bytes, rs);
+    };
+    if (split_mode == RTX_SPLIT_TILE) {
+        const uint32_t nb = (params->height + band_rows - 1) / band_rows;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t r = b % n;
+            if (r == 0) continue;
+            const uint64_t r0 = (uint64_t)b * band_rows, nr = std::min<uint64_t>(band_rows, params->height - r0);
+            HIPCHECK(peer_copy(d_frame + r0 * params->width * 3, w[r].d_share + r0 * params->width * 3, w[r].sc->device, nr * params->width * 12));
+        }
+    } else if (n > 1) {
+        float* d_stage = nullptr;
+        if ((rc = multi_buffer(root, 1, fbytes, &d_stage)) != RTX_OK) return rc;
+        const uint64_t nf = npx * 3, n4 = nf / 4;
+        for (uint32_t r = 1; r < n; r++) { // rank order: the frame does not depend on which device finished first
+            HIPCHECK(peer_copy(d_stage, w[r].d_share, w[r].sc->device, fbytes));
+            hipLaunchKernelGGL(k_accum_add, dim3(blocks_for(n4 + 1, 256)), dim3(256), 0, rs, d_frame, d_stage, n4, nf);
+            HIPCHECK(hipGetLastError());
+        }
+    }
+    if (bgr_out) {
+        DevBuf bbgr;
+        HIPCHECK(bbgr.alloc(npx * 3));
+        if ((rc = rtx_resolve_device(root, d_frame, params->width, params->height, params->spp, bbgr.as<uint8_t>(), rs)) != RTX_OK) return rc;
+        HIPCHECK(hipMemcpyAsync(bgr_out, bbgr.p, npx * 3, hipMemcpyDeviceToHost, rs));
+        HIPCHECK(hipStreamSynchronize(rs));
+    }
+    if (accum_out) HIPCHECK(hipMemcpyAsync(accum_out, d_frame, fbytes, hipMemcpyDeviceToHost, rs));
+    HIPCHECK(hipStreamSynchronize(rs));
+    return RTX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

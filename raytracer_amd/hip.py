@@ -19,7 +19,8 @@ RTX_ID_UNBOUNDED = 0x80000000
 EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_create", "rtx_scene_destroy",
            "rtx_scene_device_bytes", "rtx_cull_data_build", "rtx_trace_closest", "rtx_trace_closest_device", "rtx_render",
            "rtx_render_progressive", "rtx_render_device", "rtx_resolve_device", "rtx_camera_rays", "rtx_rng_unilateral", "rtx_material_bounce",
-           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex", "rtx_tune_set", "rtx_tune_get", "rtx_tune_reset"]
+           "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex", "rtx_tune_set", "rtx_tune_get", "rtx_tune_reset", "rtx_render_multi"]
+RTX_SPLIT_TILE, RTX_SPLIT_SAMPLE = 0, 1
 RTX_SCENE_F32_TEXTURES = 1
 RTX_NOALLOC_MAX_RAYS = 1 << 18
 
@@ -45,11 +46,16 @@ def lib() -> C.CDLL:
     # starts a SECOND one, which finds no GPU (the driver gives a process's GPU VM to one runtime: "No HIP GPUs are
     # available").  Callers that share device memory with torch (bench.py, the multi-GPU path, the tests) therefore need
     # torch first — done here, so that the order of imports in user code does not matter.  RTX_NO_TORCH_PRELOAD=1 skips it.
-    if os.environ.get("RTX_NO_TORCH_PRELOAD") != "1":
+    import sys
+    if os.environ.get("RTX_NO_TORCH_PRELOAD") != "1" and "torch" not in sys.modules:
         try:
             import torch  # noqa: F401
         except ImportError:
             pass
+        except Exception as e:  # a torch that is installed but cannot load must not take librt_hip.so down with it
+            import warnings
+            warnings.warn("raytracer_amd.hip: torch is installed but failed to import (%s: %s); loading librt_hip.so without "
+                          "the preload — importing torch later in this process may then find no GPU" % (type(e).__name__, e))
     L = C.CDLL(path)
     vp, u32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
 
@@ -80,6 +86,8 @@ def lib() -> C.CDLL:
         vp, vp, C.POINTER(rtx_stats))
     sig("rtx_render_device", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), vp, vp,
         C.POINTER(rtx_stats))
+    sig("rtx_render_multi", C.c_int, C.POINTER(vp), C.c_uint32, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_uint32, C.c_uint32,
+        u8p, f32p, C.POINTER(rtx_stats))
     sig("rtx_resolve_device", C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp)
     sig("rtx_camera_rays", C.c_int, vp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
         f32p, f32p, u32p)
@@ -159,6 +167,18 @@ def make_params(width, height, spp, max_depth, seed=(1, 2), sample_range=None, b
     p.flags = flags
     p.max_paths_in_flight = max_paths_in_flight
     return p
+
+
+def render_multi(device_scenes, cam, params, split=RTX_SPLIT_TILE, band_rows=0, want_accum=True, want_bgr=True):
+    """rtx_render_multi: one frame over the devices of `device_scenes` (DeviceScene handles of the same scene), inside
+    the library — no torch.distributed, no Python thread per device.  Returns (bgr, accum, [stats per device])."""
+    n = len(device_scenes)
+    handles = (C.c_void_p * n)(*[ds.handle for ds in device_scenes])
+    bgr = np.zeros((params.height, params.width, 3), np.uint8) if want_bgr else None
+    acc = np.zeros((params.height, params.width, 3), np.float32) if want_accum else None
+    st = (rtx_stats * n)()
+    _check(lib().rtx_render_multi(handles, n, C.byref(cam), C.byref(params), split, band_rows, _p(bgr, C.c_uint8), _p(acc, C.c_float), st))
+    return bgr, acc, [stats_dict(x) for x in st]
 
 
 def cull_data(desc):

@@ -252,6 +252,7 @@ def lib() -> C.CDLL:
     sig("Render_Stop", None, vp)
     sig("Render_Samples_Done", C.c_uint32, vp)
     sig("Render_Set_Device", None, C.POINTER(RenderCtx), C.c_int)
+    sig("Render_Set_Devices", C.c_bool, C.POINTER(RenderCtx), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32)
     sig("Render_Status", C.c_int, C.POINTER(RenderCtx), C.POINTER(rtx_stats))
     _lib = L
     return L

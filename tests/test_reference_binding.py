@@ -56,10 +56,14 @@ def test_reference_side_flattener_equals_scene_flatten(built_scenes, scene, tmp_
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,w,h,spp,depth", [("materials", 128, 72, 4, 8), ("dragon1", 96, 54, 8, 8)])
-def test_reference_render_loop_through_render_start_hip(built_scenes, device_scenes, scene, w, h, spp, depth, tmp_path):
+@pytest.mark.parametrize("scene,w,h,spp,depth,devices", [("materials", 128, 72, 4, 8, None), ("dragon1", 96, 54, 8, 8, None), ("dragon1", 96, 54, 8, 8, "0,0,0")])
+def test_reference_render_loop_through_render_start_hip(built_scenes, device_scenes, scene, w, h, spp, depth, devices, tmp_path):
+    """devices = "0,0,0": RTX_DEVICES makes Render_Start_HIP share the frame among three scene handles through rtx_render_multi
+    (tile split; on the one-GPU box all on device 0) — the image is still rtx_render's, byte for byte."""
     out = str(tmp_path / "frame.bin")
     env = dict(os.environ, RTX_HIP_LIB=os.path.join(LIB_DIR, "librt_hip.so"), RTX_SEED_LO="1", RTX_SEED_HI="2")
+    if devices:
+        env["RTX_DEVICES"] = devices
     exe = O.ref_binary("parity")
     r = subprocess.run([exe, scenes.write_recipe(scene), assets.cache_dir(), "render_hip", str(w), str(h), str(spp), str(depth), out],
                        capture_output=True, text=True, timeout=300, env=env)

@@ -37,8 +37,11 @@ rm -rf "$OUT/trace"
 # HBM-side traffic of the closest-hit kernel per launch (timed frame = the last 8 k_trace dispatches):
 # FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, json, sys
+import csv, hashlib, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
+h = hashlib.sha256()
+for f in ("rt_hip.hip", "rtx_device.h", "kd_build.h"):  # = bench.py kernel_source_hash(): the build these counters belong to
+    h.update(open(os.path.join("raytracer_amd", "csrc", f), "rb").read())
 bench = json.loads(open("%s/bench.json" % out).read().strip().splitlines()[-1])
 traced = bench["config"]["rays_per_frame"] - bench["config"]["rays_answered_in_shade"]  # rays handed to the closest-hit kernel
 def table(name):
@@ -66,7 +69,7 @@ d = {"workload": "dragon1 1920x1080 64spp d8", "hbm_bytes_per_launch": sum(per_l
      "per_launch": {"SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_THREAD_CYCLES_VALU": sq["SQ_THREAD_CYCLES_VALU"], "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"],
                     "lane_utilisation": [t / (64.0 * a) for t, a in zip(sq["SQ_THREAD_CYCLES_VALU"], sq["SQ_ACTIVE_INST_VALU"])]},
      "valu_insts_per_frame": sum(sq["SQ_INSTS_VALU"]), "rays_traced_per_frame": traced,
-     "valu_insts_per_traced_ray": sum(sq["SQ_INSTS_VALU"]) / traced, "measured_at": tag}
+     "valu_insts_per_traced_ray": sum(sq["SQ_INSTS_VALU"]) / traced, "measured_at": tag, "kernel_source_hash": h.hexdigest()[:16]}
 json.dump(d, open("%s/traffic.json" % out, "w"), indent=1)
 print(json.dumps({k: v for k, v in d.items() if not isinstance(v, list)}, indent=1))
 PY
