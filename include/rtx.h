@@ -255,7 +255,8 @@ int rtx_trace_closest_device(rtx_scene* scene, size_t n, const float* d_rays, ui
  * RTX_NOALLOC_MAX_RAYS rays (10 MB) that every GPU the library runs on holds until the process ends; a batch
  * beyond that is refused with RTX_E_LIMIT.  All calls on one GPU — whatever the scene or the stream — share that
  * GPU's array: calls that overlap on one GPU race; serialise them (one stream, or events).  RTX_TRACE_UNIT_DIR
- * and RTX_TRACE_LITERAL as above; RTX_RENDER_COUNT_VISITS is refused. ---- */
+ * and RTX_TRACE_LITERAL as above; RTX_RENDER_COUNT_VISITS is refused.  The calling thread's current device is the same
+ * after the call as before it (every other entry point that takes a scene leaves the scene's device current). ---- */
 #define RTX_NOALLOC_MAX_RAYS (1u << 18)
 int rtx_closest_hit_noalloc(rtx_scene* scene, size_t n, const float* d_origin_xyz, const float* d_dir_xyz,
                             uint32_t* d_prim_id, float* d_t, float* d_position_xyz, float* d_normal_xyz, float* d_uv,

@@ -2735,7 +2735,17 @@ extern "C" int rtx_closest_hit_noalloc(rtx_scene* sc, size_t n, const float* d_o
     if (flags & RTX_RENDER_COUNT_VISITS) return fail(RTX_E_INVALID, "rtx_closest_hit_noalloc has no visit counters: use rtx_trace_closest");
     if (!sc->noalloc_scratch) return fail(RTX_E_HIP, "the scratch array has no address on this device");
     if (n == 0) return RTX_OK;
-    HIPCHECK(hipSetDevice(sc->device));
+    // asynchronous, and meant for loops next to other GPU code: the caller's current device is put back on every return path
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    int cur = -1;
+    HIPCHECK(hipGetDevice(&cur));
+    if (cur != sc->device) {
+        HIPCHECK(hipSetDevice(sc->device));
+        guard.prev = cur;
+    }
     hipStream_t     st = (hipStream_t)stream;
     NoAllocScratch* sx = (NoAllocScratch*)sc->noalloc_scratch; // device address: only ever handed to kernels and hipMemsetAsync
     // every ray of the batch overwrites its own slots of rays[] and hits[] (stride n), and launch_trace clears the

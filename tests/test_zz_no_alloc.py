@@ -77,3 +77,43 @@ def test_noalloc_entry_limits(device_scenes):
     with pytest.raises(hip.RtxError):
         ds.closest_hit_noalloc(16, buf.data_ptr(), buf.data_ptr(), flags=hip.RTX_RENDER_COUNT_VISITS)
     ds.closest_hit_noalloc(0, 0, 0)  # empty batch: nothing to do
+
+
+def test_noalloc_entry_allocates_nothing(device_scenes):
+    """The property the entry point exists for: it can be captured into a HIP graph — a hipMalloc, hipFree or
+    event creation inside a capture fails or invalidates it — and replaying the graph gives rtx_trace_closest's bits; the
+    free device memory is the same before and after plain calls."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ds = device_scenes("teapot")
+    g = golden("trace_teapot.npz")
+    o, d = g["rays"][:, :3].copy(), g["rays"][:, 3:].copy()
+    n = len(o)
+    want = ds.trace_closest(o, d)
+    to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    out = dict(prim_id=torch.zeros(n, dtype=torch.int32, device=dev), t=torch.zeros(n, device=dev), position=torch.zeros(n, 3, device=dev),
+               normal=torch.zeros(n, 3, device=dev), uv=torch.zeros(n, 2, device=dev), front=torch.zeros(n, dtype=torch.uint8, device=dev))
+
+    def call(stream):
+        ds.closest_hit_noalloc(n, to.data_ptr(), td.data_ptr(), out["prim_id"].data_ptr(), out["t"].data_ptr(), out["position"].data_ptr(),
+                               out["normal"].data_ptr(), out["uv"].data_ptr(), out["front"].data_ptr(), stream=stream.cuda_stream)
+
+    side = torch.cuda.Stream(dev)
+    call(side)  # warm-up outside the capture (the first call on a scene asks the runtime for the kernel's occupancy)
+    side.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(3):
+        call(side)
+    side.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        call(torch.cuda.current_stream(dev))
+    for v in out.values():
+        v.zero_()
+    torch.cuda.synchronize(dev)
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    got["prim_id"] = got["prim_id"].view(np.uint32)
+    _same(got, want)
