@@ -32,6 +32,7 @@ def lib():
         dp = C.POINTER(rtx_scene_desc)
         L.oracle_trace.argtypes = [dp, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
         L.oracle_trace_culled.argtypes = [dp, C.POINTER(C.c_uint16), f32p, u8p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u64p, u32p]
+        L.oracle_trace_speculative.argtypes = [dp, C.POINTER(C.c_uint16), f32p, u8p, C.c_size_t, f32p, f32p, C.c_int, u32p, f32p, f32p, f32p, f32p, u8p, u32p]
         L.oracle_render.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), f32p, u8p, u64p, C.c_int]
         L.oracle_render_pixels.argtypes = [dp, C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, f32p, u64p, C.c_int]
         L.oracle_camera_rays.argtypes = [C.POINTER(rtx_camera), C.POINTER(rtx_render_params), C.c_size_t, u32p, u32p,
@@ -68,6 +69,24 @@ def trace(desc, origin, direction, unit_dir=False, cull=None):
     assert rc == 0
     out["visits"] = vis
     out["steps"] = steps
+    return out
+
+
+def trace_speculative(desc, origin, direction, cull=None, unit_dir=True):
+    """The speculative replay (checker of k_trace_long): every reachable subtree is walked, the accepting leaf that comes first
+    in the literal visiting order answers.  cull as in trace()."""
+    o = np.ascontiguousarray(origin, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
+    n = len(o)
+    out = dict(prim_id=np.empty(n, np.uint32), t=np.empty(n, np.float32), position=np.empty((n, 3), np.float32),
+               normal=np.empty((n, 3), np.float32), uv=np.empty((n, 2), np.float32), front=np.empty(n, np.uint8), steps=np.zeros(n, np.uint32))
+    qbox = np.ascontiguousarray(cull[0], np.uint16) if cull is not None else None
+    info = np.ascontiguousarray(cull[1], np.float32) if cull is not None else None
+    flags = np.ascontiguousarray(cull[2], np.uint8) if cull is not None and len(cull) > 2 else None
+    rc = lib().oracle_trace_speculative(desc, _p(qbox, C.c_uint16), _p(info, C.c_float), _p(flags, C.c_uint8), n, _p(o, C.c_float), _p(d, C.c_float), int(unit_dir),
+                                        _p(out["prim_id"], C.c_uint32), _p(out["t"], C.c_float), _p(out["position"], C.c_float), _p(out["normal"], C.c_float),
+                                        _p(out["uv"], C.c_float), _p(out["front"], C.c_uint8), _p(out["steps"], C.c_uint32))
+    assert rc == 0
     return out
 
 

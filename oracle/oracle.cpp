@@ -278,11 +278,24 @@ struct Cull {
     vec3 nol;    // -(o - lo), one rounding per axis
 };
 
+typedef unsigned __int128 u128;
 struct Scene {
     const rtx_scene_desc* d;
     u64                   nInner, nLeaf, nPrim; // visit counters (per thread copy)
     Cull*                 cull;
     u64                   nCulled;
+    // the place of the walk in the literal visiting order (depth-first, origin side before opposite side): bit (127 - level)
+    // of `key` is set where the path took the opposite side of a two-sided inner node.  Bookkeeping for the speculative
+    // replay (oracle_trace_speculative) only; the walk itself never reads it unless `speculative` is set.
+    u128 key;
+    int  level;
+    // speculative replay (checker of the GPU library's k_trace_long): a leaf that accepts a hit does NOT end the
+    // walk — it is noted if it comes before the best one noted so far in the visiting order, and the walk goes on through
+    // every subtree the sequential walk could reach; subtrees that come after the best leaf noted are skipped
+    bool    speculative, spec_any;
+    u128    spec_key;
+    u32     spec_obj;
+    HitInfo spec_hit;
 };
 
 static void cull_begin_ray(Cull* c, const Ray* ray)
@@ -302,15 +315,23 @@ static void cull_begin_ray(Cull* c, const Ray* ray)
 // a box plane's ray parameter, as the device computes it: fma(float(q), scale, -(o - lo)) * inv
 static inline f32 plane_t(u32 q, f32 scale, f32 nol, f32 inv) { return fmaf((f32)q, scale, nol) * inv; }
 
-static bool cull_node(const Cull* c, u32 node, f32 tMax)
+// the part [tn, tf] of {0 <= t <= kt * tMax} the ray spends inside a node's box (the device's box_range); false: never cull
+static bool cull_range(const Cull* c, u32 node, f32 tMax, f32* tn, f32* tf)
 {
     const uint16_t* q = c->qbox + 6ull * node;
     const f32 t1x = plane_t(q[0], c->scale.x, c->nol.x, c->inv.x), t2x = plane_t(q[3], c->scale.x, c->nol.x, c->inv.x);
     const f32 t1y = plane_t(q[1], c->scale.y, c->nol.y, c->inv.y), t2y = plane_t(q[4], c->scale.y, c->nol.y, c->inv.y);
     const f32 t1z = plane_t(q[2], c->scale.z, c->nol.z, c->inv.z), t2z = plane_t(q[5], c->scale.z, c->nol.z, c->inv.z);
-    const f32 tn  = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
-    const f32 tf  = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
-    return c->ok && !(q[0] == 0xFFFFu && q[3] == 0u) && tn > tf;
+    *tn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    *tf = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * c->kt));
+    return !(q[0] == 0xFFFFu && q[3] == 0u);
+}
+
+static bool cull_node(const Cull* c, u32 node, f32 tMax)
+{
+    f32        tn, tf;
+    const bool bounded = cull_range(c, node, tMax, &tn, &tf);
+    return c->ok && bounded && tn > tf;
 }
 
 struct Prim { // what the reference calls Object*: a pool reference
@@ -461,6 +482,10 @@ static bool CheckHitLeafNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, 
         }
     }
     if (objClosest != 0xFFFFFFFFu) {
+        if (sc->speculative) { // note it, and walk on as if nothing had been found
+            if (!sc->spec_any || sc->key < sc->spec_key) sc->spec_any = true, sc->spec_key = sc->key, sc->spec_obj = objClosest, sc->spec_hit = hitClosest;
+            return false;
+        }
         *hit        = hitClosest;
         objHit->ref = objClosest;
         return true;
@@ -510,9 +535,14 @@ static bool CheckHitInternalNode(Scene* sc, u32 node, const Ray* ray, Prim* objH
             originSide   = left;
             oppositeSide = right;
         }
+        const u128 key   = sc->key; // (bookkeeping of the range replay: where the walk is in the visiting order)
+        const int  level = sc->level;
+        sc->level        = level + 1;
         if (CheckHitNextNode(sc, originSide, ray, objHit, hit, tMaxNew)) {
             return true;
         } else if (tMaxNew == tIntersect) {
+            sc->key   = key | ((u128)1 << (127 - (level < 127 ? level : 127)));
+            sc->level = level + 1;
             return CheckHitNextNode(sc, oppositeSide, ray, objHit, hit, tMax);
         } else {
             return false;
@@ -522,6 +552,7 @@ static bool CheckHitInternalNode(Scene* sc, u32 node, const Ray* ray, Prim* objH
 
 static bool CheckHitNextNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, HitInfo* hit, f32 tMax) // :458
 {
+    if (sc->speculative && sc->spec_any && sc->key > sc->spec_key) return false; // this subtree comes after the best leaf noted
     if (sc->cull && !(sc->cull->flags && (sc->cull->flags[node] & 2u)) && cull_node(sc->cull, node, tMax)) { // checker mode only, see struct Cull
         sc->nCulled++;
         return false;
@@ -533,6 +564,7 @@ static bool CheckHitNextNode(Scene* sc, u32 node, const Ray* ray, Prim* objHit, 
 
 static bool KDTree_HitAt(Scene* sc, const Ray* ray, Prim* objHit, HitInfo* hit) // :572
 {
+    sc->key = 0, sc->level = 0;
     return CheckHitNextNode(sc, sc->d->root_index, ray, objHit, hit, INF);
 }
 
@@ -1165,7 +1197,9 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* q
                                    const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
                                    uint8_t* front, uint64_t* visits3, uint32_t* steps_per_ray)
 {
-    Scene sc = {desc, 0, 0, 0, NULL, 0};
+    Scene sc;
+    memset(&sc, 0, sizeof sc);
+    sc.d = desc;
     Cull  cull;
     if (qbox6) {
         cull.qbox   = qbox6;
@@ -1199,6 +1233,64 @@ extern "C" int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* q
     if (visits3) {
         visits3[0] = sc.nInner, visits3[1] = sc.nLeaf, visits3[2] = sc.nPrim;
         if (qbox6) visits3[3] = sc.nCulled; // 4 counters in checker mode
+    }
+    return 0;
+}
+
+// The speculative replay (checker of the GPU library's k_trace_long; not part of the reference).  k_trace_long
+// walks the pending far subtrees of a long walk ahead of time, on other lanes, and takes — of all leaves that accept a hit —
+// the one that comes first in the literal visiting order.  Here the (culled) walk goes through EVERY subtree the sequential
+// walk could reach, whatever an earlier leaf found (a superset of what any schedule of the kernel visits; subtrees that come
+// after the best leaf noted so far are skipped, as the kernel drops them), and the answer is the accepting leaf with the
+// smallest key.  Must equal oracle_trace on every ray.  steps (may be NULL): node and primitive visits per ray.
+extern "C" int oracle_trace_speculative(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, const uint8_t* node_flags, size_t n,
+                                        const float* o, const float* dxyz, int unit_dir, uint32_t* pid, float* t, float* pos, float* nrm, float* uv,
+                                        uint8_t* front, uint32_t* steps)
+{
+    Scene sc;
+    memset(&sc, 0, sizeof sc);
+    sc.d = desc;
+    Cull cull;
+    if (qbox6) {
+        cull.qbox  = qbox6;
+        cull.flags = node_flags;
+        cull.c     = vec(info14[0], info14[1], info14[2]);
+        cull.ro2   = info14[3];
+        cull.kt    = info14[4];
+        cull.lo    = vec(info14[5], info14[6], info14[7]);
+        cull.scale = vec(info14[8], info14[9], info14[10]);
+        sc.cull    = &cull;
+    }
+    for (size_t i = 0; i < n; i++) {
+        vec3 org = vec(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        vec3 dir = vec(dxyz[3 * i], dxyz[3 * i + 1], dxyz[3 * i + 2]);
+        Ray  ray = unit_dir ? Ray_FromUnit(org, dir) : Ray_Make(org, dir);
+        if (sc.cull) cull_begin_ray(&cull, &ray);
+        const u64 before = sc.nInner + sc.nLeaf + sc.nPrim + sc.nCulled;
+        sc.speculative = true, sc.spec_any = false;
+        Prim    dummy = {0xFFFFFFFFu};
+        HitInfo dummy_hit;
+        memset(&dummy_hit, 0, sizeof dummy_hit);
+        (void)KDTree_HitAt(&sc, &ray, &dummy, &dummy_hit); // reports nothing: every accepting leaf is only noted
+        sc.speculative = false;
+        // Scene_ClosestHit's merge with the unbounded list (scene.c:100-143)
+        Prim    obj_u = {0xFFFFFFFFu};
+        HitInfo hit_u;
+        memset(&hit_u, 0, sizeof hit_u);
+        hit_u.tIntersect = INF;
+        const bool hu = Scene_ClosestHitInArray(&sc, &ray, &obj_u, &hit_u);
+        Prim       obj = {sc.spec_obj};
+        HitInfo    hit = sc.spec_hit;
+        bool       h   = sc.spec_any;
+        if (hu && (!h || hit_u.tIntersect < hit.tIntersect)) obj = obj_u, hit = hit_u, h = true;
+        if (!h) memset(&hit, 0, sizeof hit);
+        if (pid) pid[i] = h ? prim_id(desc, obj.ref) : RTX_ID_MISS;
+        if (t) t[i] = hit.tIntersect;
+        if (pos) pos[3 * i] = hit.position.x, pos[3 * i + 1] = hit.position.y, pos[3 * i + 2] = hit.position.z;
+        if (nrm) nrm[3 * i] = hit.unitNormal.x, nrm[3 * i + 1] = hit.unitNormal.y, nrm[3 * i + 2] = hit.unitNormal.z;
+        if (uv) uv[2 * i] = hit.uv.x, uv[2 * i + 1] = hit.uv.y;
+        if (front) front[i] = h && hit.frontFace ? 1 : 0;
+        if (steps) steps[i] = (u32)(sc.nInner + sc.nLeaf + sc.nPrim + sc.nCulled - before);
     }
     return 0;
 }

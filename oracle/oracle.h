@@ -36,6 +36,13 @@ int oracle_trace_culled(const rtx_scene_desc* desc, const uint16_t* qbox6, const
                         float* position_xyz, float* normal_xyz, float* uv, uint8_t* front_face, uint64_t* visits,
                         uint32_t* steps_per_ray);
 
+/* The speculative replay: checker of the GPU library's k_trace_long (not part of the reference).  The walk goes
+ * through every subtree the sequential walk could reach, whatever an earlier leaf found, and answers with the accepting leaf
+ * that comes first in the literal visiting order (qbox6 == NULL: without the culling).  Must equal oracle_trace on every ray. */
+int oracle_trace_speculative(const rtx_scene_desc* desc, const uint16_t* qbox6, const float* info14, const uint8_t* node_flags, size_t n,
+                             const float* origin_xyz, const float* dir_xyz, int unit_dir, uint32_t* prim_id, float* t, float* position_xyz,
+                             float* normal_xyz, float* uv, uint8_t* front_face, uint32_t* steps_per_ray);
+
 /* Seeded RenderPixel over the frame partition described by params (same meaning as rtx_render).
  * cum_out: W*H*3 f32 sums (rows not assigned are left untouched); bgr_out: W*H*3 u8 or NULL.
  * rays_at_depth: RTX_MAX_DEPTH counters or NULL.  n_threads <= 0: one thread. */

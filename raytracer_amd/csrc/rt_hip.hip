@@ -31,6 +31,7 @@
 #include "rtx_device.h"
 
 #define RTX_MAX_LANES 4 // slabs of a frame in flight at once (rtx_render_device)
+#define LONG_CAP (1u << 19) // entries of a long list (k_trace_long): a resident grid holds at most 8192 waves x 64 walks
 
 // ray binning between bounce passes (see k_bin_count): cells per axis = 2^BIN_CELL_BITS, times 8 direction octants
 #ifndef BIN_CELL_BITS
@@ -68,11 +69,14 @@ static int fail(int code, const char* fmt, ...)
 // and only sets the defaults; after that a call's behaviour depends on its arguments and on rtx_tune_set, never on the
 // environment of the moment.  Change a knob only while no call is in flight.
 // ---------------------------------------------------------------------------------------------
+#ifndef LONG_AFTER_DEFAULT
+#define LONG_AFTER_DEFAULT (-1) // off until it has been measured
+#endif
 #ifndef TAIL_MAX_DEFAULT
 #define TAIL_MAX_DEFAULT (2ll << 20) // sweep on a rank's share of the bench frame at N = 8 and 4 (tools/dbg/share8.py): longer queues are better off with a pass per depth
 #endif
 enum { K_OVERLAP, K_SORT_DEPTH, K_SORT_MIN, K_SORT_EVERY, K_TAIL_MAX, K_TAIL_SHADE_MIN, K_JUMP_TABLE, K_RAYGEN_LEAN, K_EARLY_MISS, K_FAST_DIV,
-       K_BAND_TILES, K_TRACE_CHUNK, K_AHEAD, K_TILE_INTERLEAVE, K_COUNT };
+       K_BAND_TILES, K_TRACE_CHUNK, K_AHEAD, K_TILE_INTERLEAVE, K_LONG_AFTER, K_LONG_ALL, K_COUNT };
 struct Knob {
     const char* name;
     long long   dflt, value;
@@ -93,6 +97,8 @@ static Knob g_knobs[K_COUNT] = {
     {"TRACE_CHUNK", 0, 0, 0, 4096},           // rays per work grab of the closest-hit kernel (16 at least); 0 = by queue length
     {"AHEAD", 1, 0, 0, 1},                    // 0: a depth's closest-hit pass is launched only after the host has read the queue's length
     {"TILE_INTERLEAVE", 4096, 0, 0, 1ll << 40}, // camera pass: the queue's eight parts (one per XCD) are runs of this many rays dealt out in turn; 0: its eighths
+    {"LONG_AFTER", LONG_AFTER_DEFAULT, 0, -1, 1ll << 20}, // walks still in flight this many iterations after the queue has run dry go to k_trace_long; -1 = never
+    {"LONG_ALL", 0, 0, 0, 1},                 // 1: EVERY ray goes through k_trace_long instead of the persistent kernel (the tests' mode)
 };
 static std::atomic<int> g_multi_in_flight{0}; // rtx_render_multi calls running: the table is read-only meanwhile
 static std::once_flag g_knobs_once;
@@ -185,6 +191,8 @@ struct rtx_scene {
     hipEvent_t          ev_fork, ev_join[RTX_MAX_LANES - 1];
     unsigned long long* h_alive; // pinned: the surviving-path counts of the lanes
     bool     cull_useful; // the scene's boxes are tight enough for the culled kernel to pay (build_cull_data)
+    uint32_t* d_long;     // RTX_MAX_LANES long lists of LONG_CAP entries (k_trace_long), one per lane of the render loop
+    uint32_t  tree_depth; // desc.max_depth
     void*    multi_buf[2];   // rtx_render_multi: this scene's share of the frame (f32 x 3 x W x H) and, on the root, the staging of the peers' shares
     uint64_t multi_bytes[2];
     hipStream_t multi_stream;
@@ -877,6 +885,18 @@ extern "C" int rtx_scene_create_ex(const rtx_scene_desc* d, int device, uint32_t
         UP(upload(sc, zeros.data(), zeros.size(), &c));
         sc->d_counters = (uint64_t*)c;
     }
+    {
+        void* p = nullptr;
+        const size_t bytes = (size_t)RTX_MAX_LANES * LONG_CAP * sizeof(uint32_t);
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            rtx_scene_destroy(sc);
+            return fail(RTX_E_NOMEM, "cannot allocate the long-walk lists");
+        }
+        sc->allocs.push_back(p);
+        sc->bytes += bytes;
+        sc->d_long     = (uint32_t*)p;
+        sc->tree_depth = d->max_depth;
+    }
     tm.lap("the rest");
     S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
     S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root_literal = d->root_index;
@@ -1199,7 +1219,12 @@ struct TailArgs {
     uint32_t            shade_min; // lanes that must wait before the shade block runs
     uint32_t            il_len;   // != 0: parts are not eighths of the queue but rows of il_len rays dealt out in turn (see the grab loop)
     const unsigned long long* n_dev; // not null: the queue's length is read here (the pass was launched before the host knew it; `n` is an upper bound)
+    uint32_t*           long_list;  // not null: walks still in flight `long_after` iterations after the queue has run dry are handed
+    uint32_t            long_after; //           to k_trace_long (their ray indices go here, work[LONG_COUNT] counts them)
 };
+// slots of the persistent kernels' `work` array (64 u64, cleared per launch; [8 p] = rays handed out of part p)
+enum { LONG_DRY = 1, LONG_COUNT = 2, LONG_CURSOR = 3 };
+
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace_persist(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n,
@@ -1413,6 +1438,9 @@ enum { ST_INNER = 0, ST_LEAF = 1, ST_SHADE = 2, ST_DONE = 3, ST_IDLE = 4 };
 #ifndef DRAIN_MIN
 #define DRAIN_MIN 1u
 #endif
+#ifndef LONG_POLL
+#define LONG_POLL 128u // iterations without a refill after which a wave asks whether the launch is draining (k_trace_flat<.., LONG>)
+#endif
 #ifndef LDS_SLOTS
 #define LDS_SLOTS 8 // power of two; 8 slots = 4 KB per wave (16 slots: fewer blocks per CU, 14 % slower)
 #endif
@@ -1463,7 +1491,7 @@ DEV uint32_t wave_scan_max(uint32_t v) // inclusive prefix maximum over the lane
 DEV float lane_read(float v, uint32_t src) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)__float_as_uint(v))); }
 DEV uint32_t lane_read(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
 
-template <bool COUNT, bool CULL, bool COOP, bool TAIL = false>
+template <bool COUNT, bool CULL, bool COOP, bool TAIL = false, bool LONG = false>
 // (waves_per_eu(6): the walk needs 88 VGPRs as the compiler likes it, 5 waves per SIMD; held to 80 it spills two
 // values that only the refill touches and runs 6 waves per SIMD — 95.0 -> 91.8 ms; 7 waves cost 8 spills and lose)
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? TAIL_WAVES : 6))) void k_trace_flat(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n_bound,
@@ -1496,6 +1524,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
     uint32_t refill_at = refill_min; // wave-uniform: free lanes at which the wave stops to refill (64 once the queue has run dry: then to leave)
     uint32_t part      = xcc_id(), parts_left = 8; // wave-uniform
     int      state     = ST_IDLE;
+    // Long walks (LONG).  A launch used to end on its longest walk — one ray skimming the model through
+    // hundreds of leaves while the chip idles.  Here a wave that knows the queue has run dry everywhere gives its walks
+    // `long_after` more iterations and then hands the ones still in flight to k_trace_long, which walks each of them with
+    // all 64 lanes of a wave.  The loop pays one countdown for it: `patience` is wound up whenever the wave loads rays; a wave
+    // that has not loaded any for LONG_POLL iterations (it is full of long walks, and never asks the queue) looks at the
+    // flag the first wave to find the queue dry has raised.  (wave-uniform)
+    uint32_t patience = LONG_POLL;
 
     f3       o = mk3(0, 0, 0), d = mk3(0, 0, 1), inv = mk3(0, 0, 0), odd = mk3(0, 0, 0);
     u3       rot = {0, 0, 0}; // CULL: 16 on the axes where the direction is negative (box_missed2)
@@ -1576,6 +1611,32 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         // (The loop's scheduling is scalar code, and at this kernel's issue rate a scalar instruction costs about half a vector
         // one — 40 of them per iteration, added for the measurement, cost 5.7 ms per frame —, so the common path through here is
         // one ballot, one count and one comparison: refill_at is refill_min, or 64 once the queue has run dry.)
+        if (LONG && --patience == 0u) {
+            if (exhausted) {
+                // hand over: the ray indices of the walks in flight go to the long list, one atomic per wave
+                const bool     walking = state == ST_INNER || state == ST_LEAF;
+                const uint64_t wm      = __builtin_amdgcn_ballot_w64(walking);
+                if (wm) {
+                    unsigned long long at = 0;
+                    if (lane == 0) at = atomicAdd(work + LONG_COUNT, (unsigned long long)__popcll(wm));
+                    at = wave_bcast_u64(at);
+                    if (walking) {
+                        ta.long_list[(uint32_t)at + (uint32_t)__popcll(wm & lt_mask)] = ridx;
+                        state = ST_IDLE;
+                    }
+                }
+                patience = 0x7FFFFFFFu; // (all lanes are free now: the loop's head writes the finished walks' records and leaves)
+            } else {
+                const unsigned long long dry = __hip_atomic_load(work + LONG_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                patience = LONG_POLL;
+                if (__builtin_amdgcn_readfirstlane((uint32_t)dry) != 0u) {
+                    // (rays of this wave's last grab that it has not loaded yet go first: any free lane takes one, and the
+                    // grab loop then finds the parts empty by itself)
+                    if (next >= end) exhausted = true, refill_at = 64u, leaf_min = DRAIN_MIN, inner_min = DRAIN_MIN, patience = ta.long_after + 1u, parts_left = 0;
+                    else refill_at = 1u;
+                }
+            }
+        }
         const uint64_t idle  = __builtin_amdgcn_ballot_w64(state >= ST_DONE);
         const uint32_t nidle = (uint32_t)__popcll(idle);
         if (nidle >= refill_at) {
@@ -1622,9 +1683,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
                     part = (part + 1) & 7u;
                     parts_left--;
                 }
-                if (parts_left == 0) exhausted = true, refill_at = 64u, leaf_min = DRAIN_MIN, inner_min = DRAIN_MIN;
+                if (parts_left == 0) {
+                    exhausted = true, refill_at = 64u, leaf_min = DRAIN_MIN, inner_min = DRAIN_MIN;
+                    if (LONG) {
+                        patience = ta.long_after + 1u;
+                        if (lane == 0) __hip_atomic_store(work + LONG_DRY, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             if (!exhausted) {
+                if (LONG) patience = LONG_POLL;
                 const uint32_t avail = (uint32_t)(end - next);
                 const uint32_t take  = nidle < avail ? nidle : avail;
                 const uint32_t rank  = (uint32_t)__popcll(idle & lt_mask);
@@ -2025,6 +2093,225 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(TAI
         add_visits(counters, vis);
         if (lane == 0)
             for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)&counters[8 + i], (unsigned long long)ws[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_trace_long — one long walk by the 64 lanes of a wave.
+//
+// A ray that skims the model visits hundreds of leaves one after the other; at ~1 us per dependent step that is the
+// last millisecond of every closest-hit launch, with the chip empty.  The walk (KDTree_HitAt, kdtree.c:453-577, with the
+// culling of DESIGN.md §5) is a depth-first search: near child, then — if the near subtree reported nothing and the plane
+// lies within the range — the far child with the OUTER tMax; the first leaf that accepts a hit ends it.  The tMax a node is
+// entered with depends on the path to it alone, so what a subtree reports does not depend on its elder siblings: the
+// pending far subtrees can be walked AHEAD of time.  Here a lane that is free takes a pending far subtree off a busy lane
+// (the youngest one: the next in the order) and walks it speculatively; every node carries its place in the literal
+// visiting order as a key — bit (63 - level) = 1 where the path took the far child of a two-sided inner step —, a leaf that
+// accepts a hit reports with its key, the smallest key is the walk's answer (one 64-bit LDS minimum), and whatever stands
+// behind the smallest key reported so far is dropped.  The set of nodes walked is a superset of the sequential walk's and
+// every one of them is entered with the same tMax, so the leaf with the smallest key that accepts a hit is the first leaf
+// the sequential walk finds, with the same hit: bit for bit the same record.
+// Checked: oracle_trace_speculative walks ALL reachable subtrees on the CPU and takes the smallest key (tests/test_culling_cpu.py:
+// equal to the literal oracle on the golden rays, the awkward rays and the soups), and the GPU tests send EVERY ray of the
+// golden sets, the 1080p checksums, the soups and whole frames through this kernel (knob LONG_ALL): the literal kernel's bits.
+// One ray per wave.  A tree deeper than the key has room for is walked by one lane alone (no key needed).
+// ---------------------------------------------------------------------------------------------
+#define LONG_LEVEL_MAX 57 // key bits 63 .. 6 hold the path, bits 5 .. 0 the level
+__global__ __launch_bounds__(64) void k_trace_long(SceneDev S, const float* __restrict__ rays, uint64_t stride, uint64_t n_bound, const unsigned long long* n_dev,
+                                                   uint32_t* __restrict__ hits, uint64_t hstride, const uint32_t* __restrict__ list,
+                                                   unsigned long long* work, uint32_t tree_depth)
+{
+    __shared__ unsigned long long s_best;
+    __shared__ uint4              s_res;
+    __shared__ uint4              s_mail[64];
+    const uint32_t lane    = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // rays to trace: the long list's entries, or (list == nullptr: every ray of the queue, the tests' mode) 0 .. n - 1
+    uint64_t count = list ? __hip_atomic_load(work + LONG_COUNT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (n_dev ? *n_dev : n_bound);
+    if (list && count > LONG_CAP) count = LONG_CAP;
+    const bool solo = tree_depth > LONG_LEVEL_MAX;
+    uint4      stk[RTX_STACK]; // this lane's pending far subtrees: {node, tMax, key lo, key hi} (the level rides in the key's low bits)
+
+    for (;;) {
+        unsigned long long gi = 0;
+        if (lane == 0) gi = atomicAdd(work + LONG_CURSOR, 1ull);
+        gi = wave_bcast_u64(gi);
+        if (gi >= count) break;
+        const uint32_t ridx = list ? (uint32_t)__builtin_amdgcn_readfirstlane((int)list[gi]) : (uint32_t)gi;
+        const uint64_t cs = stride ? stride : 1, rb = (uint64_t)ridx * (stride ? 1 : Q_RECORD);
+        const f3       o = mk3(rays[0 * cs + rb], rays[1 * cs + rb], rays[2 * cs + rb]);
+        const f3       d = mk3(rays[3 * cs + rb], rays[4 * cs + rb], rays[5 * cs + rb]);
+        f3       inv = vdivc(mk3(1.0f, 1.0f, 1.0f), d); // Ray_Make's cached quotients (ray.c:12-13), as k_trace_flat's refill has them
+        const f3 odd = vdivc(o, d);
+        const float big = 3.0e38f;
+        inv.x = fabsf(inv.x) > big ? copysignf(big, inv.x) : inv.x;
+        inv.y = fabsf(inv.y) > big ? copysignf(big, inv.y) : inv.y;
+        inv.z = fabsf(inv.z) > big ? copysignf(big, inv.z) : inv.z;
+        const float rx = o.x - S.cull_c[0], ry = o.y - S.cull_c[1], rz = o.z - S.cull_c[2];
+        const float r2 = rx * rx + ry * ry + rz * rz, d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+        const bool  cullOK = r2 <= S.cull_ro2 && fabsf(d2 - 1.0f) <= 1.0e-3f;
+        if (lane == 0) s_best = ~0ull;
+        LDS_ORDER();
+
+        bool               have = lane == 0; // this lane stands on a node
+        uint32_t           node = S.root, level = 0;
+        unsigned long long key  = 0;
+        float              tMax = RTX_INF;
+        int                sp   = 0;
+        for (;;) {
+            bool  produced = false, pop = false;
+            uint4 far      = make_uint4(0, 0, 0, 0);
+            LDS_ORDER();
+            if (have && !solo && (key | level) > s_best) have = false, sp = 0; // this node and all this lane holds come later in the order
+            if (have) {
+                const uint32_t* rec = S.nodes40 + (uint64_t)NODE_WORDS * node;
+                const uint4     qa = *(const uint4*)rec, qb = *(const uint4*)(rec + 4);
+                const uint2     qc = *(const uint2*)(rec + 8);
+                const uint32_t  cax = (qc.x >> 29) & 3u;
+                if (cax != 3u) { // the folded cut-off node above this one: k_trace_flat's code, CheckHitInternalNode kdtree.c:501-570
+                    const float split = __uint_as_float(qc.y);
+                    const bool  cx0 = cax == 0u, cx1 = cax == 1u;
+                    const float dA   = cx0 ? d.x : (cx1 ? d.y : d.z);
+                    const float oA   = cx0 ? o.x : (cx1 ? o.y : o.z);
+                    const float invA = cx0 ? inv.x : (cx1 ? inv.y : inv.z);
+                    const float oddA = cx0 ? odd.x : (cx1 ? odd.y : odd.z);
+                    const bool  par    = fabsf(dA) < RT_EPSILON;
+                    const float tI     = split * invA - oddA;
+                    const float tMaxN  = minf_(tMax, tI);
+                    const bool  behind = tI < RT_EPSILON;
+                    const bool  both   = !par && !behind;
+                    const bool  ge      = oA >= split;
+                    const bool  tieSide = (oA + 100.0f * dA) >= split;
+                    const bool  goRight = (!par && behind && oA == split) ? tieSide : ge;
+                    const bool  here    = goRight == ((qc.x >> 31) != 0u);
+                    pop  = !here && !(both && tMaxN == tI);
+                    tMax = (here && both) ? tMaxN : tMax;
+                }
+                const uint32_t type = qa.y >> 30, idx = qa.y & 0x3FFFFFFFu;
+                if (pop) {
+                } else if (type == 3u) { // CheckHitLeafNode, kdtree.c:475-499
+                    float    bestT = RTX_INF, bu = 0.0f, bv = 0.0f;
+                    uint32_t best  = HIT_MISS;
+                    for (uint32_t i = 0; i < qa.x; i++) {
+                        const uint32_t r = S.leaf_ref[idx + i];
+                        float          t, u = 0.0f, v = 0.0f;
+                        bool           hit;
+                        if (r & RTX_REF_SPHERE) {
+                            hit = Sphere_HitAt(S.sph[r & 0x7FFFFFFFu], o, d, RT_EPSILON, tMax, t);
+                        } else {
+                            const float4* tp = TRI_PTR(S, r);
+                            const float4  ta = tp[0], tb = tp[1];
+                            const float   tc = *(const float*)(tp + 2);
+                            hit = Triangle_HitAt(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc), o, d, RT_EPSILON, tMax, t, u, v);
+                        }
+                        if (hit && t < bestT) bestT = t, best = r, bu = u, bv = v; // strict: first in the list wins ties (:485)
+                    }
+                    if (best != HIT_MISS) { // a leaf that reports a hit: the smallest key is the walk's answer; what this lane still holds comes later
+                        const unsigned long long full = key | level;
+                        atomicMin(&s_best, full);
+                        LDS_ORDER();
+                        if (s_best == full) s_res = make_uint4(best, __float_as_uint(bestT), __float_as_uint(bu), __float_as_uint(bv));
+                        have = false, sp = 0;
+                    } else {
+                        pop = true;
+                    }
+                } else { // CheckHitInternalNode, kdtree.c:501-570, as in k_trace_flat
+                    const float    split = __uint_as_float(qa.x);
+                    const uint32_t right = qc.x & 0x1FFFFFFFu;
+                    const bool     ax0 = type == 0u, ax1 = type == 1u;
+                    const float    dA   = ax0 ? d.x : (ax1 ? d.y : d.z);
+                    const float    oA   = ax0 ? o.x : (ax1 ? o.y : o.z);
+                    const float    invA = ax0 ? inv.x : (ax1 ? inv.y : inv.z);
+                    const float    oddA = ax0 ? odd.x : (ax1 ? odd.y : odd.z);
+                    const bool     par    = fabsf(dA) < RT_EPSILON;
+                    const float    tI     = split * invA - oddA;
+                    const float    tMaxN  = minf_(tMax, tI);
+                    const bool     behind = tI < RT_EPSILON;
+                    const bool     both   = !par && !behind;
+                    const bool     ge      = oA >= split;
+                    const bool     tieSide = (oA + 100.0f * dA) >= split;
+                    const bool     goRight = (!par && behind && oA == split) ? tieSide : ge;
+                    const bool     farPending = both && tMaxN == tI;
+                    const float    tNear      = both ? tMaxN : tMax;
+                    const uint32_t nearNode = goRight ? right : idx, farNode = goRight ? idx : right;
+                    // the children's boxes against the segments they would be walked with
+                    const bool missL = cullOK && box_missed(S, qa.z, qa.w, qb.x, o, inv, goRight ? tMax : tNear);
+                    const bool missR = cullOK && box_missed(S, qb.y, qb.z, qb.w, o, inv, goRight ? tNear : tMax);
+                    const bool missNear = goRight ? missR : missL, missFar = goRight ? missL : missR;
+                    const bool pushFar  = farPending && !missFar;
+                    const unsigned long long keyFar = key | (1ull << (63u - (level < 63u ? level : 63u)));
+                    if (!missNear) {
+                        if (pushFar) {
+                            const unsigned long long kf = keyFar | (level + 1u);
+                            far      = make_uint4(farNode, __float_as_uint(tMax), (uint32_t)kf, (uint32_t)(kf >> 32));
+                            produced = true;
+                        }
+                        node = nearNode, tMax = tNear, level++;
+                    } else if (pushFar) {
+                        node = farNode, key = keyFar, level++;
+                    } else {
+                        pop = true;
+                    }
+                }
+            }
+            if (have && pop) { // this lane's next node: its own youngest pending subtree
+                if (sp > 0) {
+                    const uint4 e = stk[--sp];
+                    node = e.x, tMax = __uint_as_float(e.y);
+                    const unsigned long long kf = (unsigned long long)e.w << 32 | e.z;
+                    key = kf & ~63ull, level = (uint32_t)(kf & 63ull);
+                } else {
+                    have = false;
+                }
+            }
+            // Pending subtrees change hands: a lane with nothing to do takes the youngest pending subtree — the one just
+            // produced, else the top of the stack — of a lane that has one (lanes matched by rank through an LDS mailbox).
+            const uint64_t hungry = __builtin_amdgcn_ballot_w64(!have);
+            const uint64_t donors = solo ? 0ull : __builtin_amdgcn_ballot_w64(have && (produced || sp > 0));
+            const uint32_t nH = (uint32_t)__popcll(hungry), nD = (uint32_t)__popcll(donors);
+            const uint32_t m  = nH < nD ? nH : nD;
+            const uint32_t dRank = (uint32_t)__popcll(donors & lt_mask), hRank = (uint32_t)__popcll(hungry & lt_mask);
+            if (((donors >> lane) & 1ull) && dRank < m) {
+                if (produced) s_mail[dRank] = far, produced = false;
+                else s_mail[dRank] = stk[--sp];
+            }
+            if (produced) stk[sp++] = far;
+            LDS_ORDER();
+            if (((hungry >> lane) & 1ull) && hRank < m) {
+                const uint4 e = s_mail[hRank];
+                node = e.x, tMax = __uint_as_float(e.y);
+                const unsigned long long kf = (unsigned long long)e.w << 32 | e.z;
+                key = kf & ~63ull, level = (uint32_t)(kf & 63ull);
+                have = true, sp = 0;
+            }
+            LDS_ORDER();
+            if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+        }
+        LDS_ORDER();
+        if (lane == 0) { // FIN: Scene_ClosestHit's merge with the unbounded list (scene.c:73-98, 122-142), as k_trace_flat's write_hit
+            uint32_t ref = HIT_MISS;
+            float    tH = RTX_INF, uH = 0.0f, vH = 0.0f;
+            if (s_best != ~0ull) {
+                const uint4 w = s_res;
+                ref = w.x, tH = __uint_as_float(w.y), uH = __uint_as_float(w.z), vH = __uint_as_float(w.w);
+            }
+            float    pBest = RTX_INF;
+            uint32_t pRef  = HIT_MISS;
+            for (uint32_t i = 0; i < S.n_planes; i++) {
+                const float* pl = S.plane + 8ull * i;
+                float        tp2;
+                if (Plane_HitAt(mk3(pl[0], pl[1], pl[2]), mk3(pl[3], pl[4], pl[5]), o, d, RT_EPSILON, RTX_INF, tp2) && tp2 < pBest) {
+                    pBest = tp2;
+                    pRef  = HIT_PLANE | i;
+                }
+            }
+            if (pRef != HIT_MISS && (ref == HIT_MISS || pBest < tH)) ref = pRef, tH = pBest, uH = 0.0f, vH = 0.0f;
+            hits[0 * hstride + ridx] = ref;
+            hits[1 * hstride + ridx] = __float_as_uint(tH);
+            hits[2 * hstride + ridx] = __float_as_uint(uH);
+            hits[3 * hstride + ridx] = __float_as_uint(vH);
+        }
+        LDS_ORDER();
     }
 }
 
@@ -2605,9 +2892,70 @@ static int launch_trace(rtx_scene* sc, const float* d_rays, uint64_t stride, uin
     if (n_dev && variant < 2) return fail(RTX_E_INVALID, "this closest-hit kernel takes the queue's length from the host");
     ta.n_dev  = n_dev;
     ta.il_len = variant >= 2 && il_len < (1ull << 31) ? (uint32_t)il_len : 0u;
-    hipLaunchKernelGGL(tk.kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
+    // Long walks (k_trace_long): only the culled cooperative kernel hands walks over, never under COUNT_VISITS (the visit
+    // counts are the plain walk's), and only where `work` is a lane's counter block of this scene (the allocation-free
+    // entry point brings its own and has no list).
+    uint32_t* long_list = nullptr;
+    {
+        const ptrdiff_t off = (const uint64_t*)work - sc->d_counters;
+        if (variant == 4 && !tail && !count && off >= 16 && (off - 16) % 80 == 0 && (off - 16) / 80 < RTX_MAX_LANES && (uint64_t)nb * bs <= LONG_CAP)
+            long_list = sc->d_long + (size_t)((off - 16) / 80) * LONG_CAP;
+    }
+    static const unsigned long_blocks = getenv("RTX_LONG_BLOCKS") ? (unsigned)atoi(getenv("RTX_LONG_BLOCKS")) : 2048u; // experiments
+    if (long_list && knob(K_LONG_ALL) != 0) { // the tests' mode: every ray of the queue through k_trace_long
+        hipLaunchKernelGGL(k_trace_long, dim3(long_blocks), dim3(64), 0, st, sc->dev, d_rays, stride, n, n_dev, d_hits, hstride, (const uint32_t*)nullptr, work,
+                           sc->tree_depth);
+        HIPCHECK(hipGetLastError());
+        return RTX_OK;
+    }
+    const long long long_after = knob(K_LONG_AFTER);
+    PersistKernel kern = tk.kern;
+    if (long_list && long_after >= 0) {
+        ta.long_list = long_list, ta.long_after = (uint32_t)long_after;
+        kern = k_trace_flat<false, true, true, false, true>; // (variant 4, no COUNT, no TAIL: checked above)
+    }
+    static const bool debug = getenv("RTX_LONG_DEBUG") != nullptr; // experiments: rays handed over, the two kernels' times, per launch
+    hipEvent_t        em = nullptr;
+    if (debug) {
+        HIPCHECK(hipEventCreate(&em));
+        HIPCHECK(hipEventRecord(em, st));
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, st, sc->dev, d_rays, stride, n, d_hits, hstride, work, (uint32_t)chunk, d_counters,
                        tune | (bounce_rays && !count ? 1u << 25 : 0u) | (n_dev && knob(K_TRACE_CHUNK) <= 0 ? 1u << 26 : 0u), ta);
     HIPCHECK(hipGetLastError());
+    if (debug && !ta.long_list) {
+        hipEvent_t e0 = nullptr;
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventRecord(e0, st));
+        HIPCHECK(hipEventSynchronize(e0));
+        float ms_main = 0;
+        HIPCHECK(hipEventElapsedTime(&ms_main, em, e0));
+        fprintf(stderr, "[long] queue %llu rays: main kernel %.3f ms (no hand-over)\n", (unsigned long long)n, ms_main);
+    }
+    if (ta.long_list) {
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (debug) {
+            HIPCHECK(hipEventCreate(&e0));
+            HIPCHECK(hipEventCreate(&e1));
+            HIPCHECK(hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL(k_trace_long, dim3(long_blocks), dim3(64), 0, st, sc->dev, d_rays, stride, n, n_dev, d_hits, hstride, (const uint32_t*)long_list, work,
+                           sc->tree_depth);
+        HIPCHECK(hipGetLastError());
+        if (debug) {
+            HIPCHECK(hipEventRecord(e1, st));
+            HIPCHECK(hipEventSynchronize(e1));
+            unsigned long long c = 0;
+            float              ms = 0;
+            HIPCHECK(hipMemcpy(&c, work + LONG_COUNT, 8, hipMemcpyDeviceToHost));
+            float ms_main = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            HIPCHECK(hipEventElapsedTime(&ms_main, em, e0));
+            fprintf(stderr, "[long] queue %llu rays: main kernel %.3f ms, %llu handed over, k_trace_long %.3f ms\n", (unsigned long long)n, ms_main, c, ms);
+            (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+            (void)e2;
+        }
+    }
     return RTX_OK;
 }
 

@@ -374,6 +374,21 @@ DEV bool box_missed(const SceneDev& S, uint32_t wx, uint32_t wy, uint32_t wz, f3
     return wx != 0x0000FFFFu && tn > tf;
 }
 
+// The same box as a parameter range: [tn, tf] = the part of {t >= 0, t <= kt * tMax} the ray spends inside the box (empty:
+// tn > tf, box_missed's verdict); false for a box marked "never cull".  Same operations as box_missed.  For the ray-range
+// tasks of k_trace_long: every operation is monotone in the box's planes, so a box nested in another on the grid (a child
+// in its parent) has a range nested in the other's.
+DEV bool box_range(const SceneDev& S, uint32_t wx, uint32_t wy, uint32_t wz, f3 o, f3 inv, float tMax, float& tn, float& tf)
+{
+    const float nx = -(o.x - S.cull_lo[0]), ny = -(o.y - S.cull_lo[1]), nz = -(o.z - S.cull_lo[2]);
+    const float t1x = fmaf(BOX_LO(wx), S.cull_scale[0], nx) * inv.x, t2x = fmaf(BOX_HI(wx), S.cull_scale[0], nx) * inv.x;
+    const float t1y = fmaf(BOX_LO(wy), S.cull_scale[1], ny) * inv.y, t2y = fmaf(BOX_HI(wy), S.cull_scale[1], ny) * inv.y;
+    const float t1z = fmaf(BOX_LO(wz), S.cull_scale[2], nz) * inv.z, t2z = fmaf(BOX_HI(wz), S.cull_scale[2], nz) * inv.z;
+    tn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+    tf = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), tMax * S.cull_kt));
+    return wx != 0x0000FFFFu;
+}
+
 // (The walk's form: `rot` = 16 on an axis where the direction is negative, else 0.  Rotating a word by it puts the plane the
 // ray meets first into the low half and the other into the high half — with min <= max on the grid and a monotone
 // decode that IS min / max of the two ray parameters, so the twelve v_min / v_max of the slab test become six rotations

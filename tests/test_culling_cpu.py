@@ -36,6 +36,11 @@ def test_culled_equals_literal_on_golden_rays(built_scenes, scene):
     cul = O.trace(sc.desc, rec["o"], rec["d"], unit_dir=True, cull=cull)
     _same(lit, cul)
     assert cul["visits"][:3].sum() < lit["visits"].sum()
+    # the speculative replay (checker of k_trace_long): every reachable subtree walked, the accepting leaf
+    # that comes first in the visiting order answers — with and without the culling
+    _same(lit, O.trace_speculative(sc.desc, rec["o"], rec["d"], cull=cull))
+    _same(lit, O.trace_speculative(sc.desc, rec["o"], rec["d"]))
+    _same(O.trace(sc.desc, g["rays"][:, :3], g["rays"][:, 3:]), O.trace_speculative(sc.desc, g["rays"][:, :3], g["rays"][:, 3:], cull=cull, unit_dir=False))
 
 
 def test_culled_equals_literal_on_awkward_rays(built_scenes):
@@ -62,6 +67,7 @@ def test_culled_equals_literal_on_awkward_rays(built_scenes):
     d[: n // 10] = 0.0
     d[np.arange(n // 10), axis] = np.where(rng.random(n // 10) < 0.5, 1.0, -1.0)
     _same(O.trace(sc.desc, o, d, unit_dir=True), O.trace(sc.desc, o, d, unit_dir=True, cull=cull))
+    _same(O.trace(sc.desc, o, d, unit_dir=True), O.trace_speculative(sc.desc, o, d, cull=cull))
 
     # origins beyond the culling radius, huge coordinates, non-unit and non-finite directions: the walk
     # must fall back to the literal one ray by ray (checker counts no culled node for them)
@@ -77,6 +83,8 @@ def test_culled_equals_literal_on_awkward_rays(built_scenes):
     a, b = O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True), O.trace(sc.desc, inside[:3000], bad_d, unit_dir=True, cull=cull)
     _same(a, b)
     assert b["visits"][3] == 0
+    c = O.trace_speculative(sc.desc, inside[:3000], bad_d, cull=cull)
+    assert np.array_equal(a["prim_id"], c["prim_id"])
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -92,6 +100,7 @@ def test_culled_equals_literal_on_random_scenes(seed):
         lit = O.trace(sc.desc, o, d, unit_dir=True)
         cul = O.trace(sc.desc, o, d, unit_dir=True, cull=cull)
         _same(lit, cul)
+        _same(lit, O.trace_speculative(sc.desc, o, d, cull=cull))  # k_trace_long's rule: the first accepting leaf in the visiting order
         if seed % 6 >= 2 or seed % 3 >= 1:  # (a lone triangle or two are rarely hit)
             assert (lit["prim_id"] != 0xFFFFFFFF).sum() > len(o) // 100
         if seed % 6 >= 3:
