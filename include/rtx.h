@@ -213,6 +213,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
  * return exactly the floats of the f32 image at a quarter of the footprint.  RTX_SCENE_F32_TEXTURES keeps every
  * texture as handed over (the tests compare the two). */
 #define RTX_SCENE_F32_TEXTURES 1u
+/* A skybox face that is a single texel (Texture_Import_Color, src/gfx/texture.c:49-70: the constant skies of the BASELINE
+ * configs) is answered without the lookup: Texture_ColorAt returns that texel whatever u and v are, so Skybox_ColorAt's two
+ * quotients and three dependent loads buy nothing.  RTX_SCENE_SKY_LOOKUP keeps the full lookup for every face (same floats). */
+#define RTX_SCENE_SKY_LOOKUP 2u
 int rtx_scene_create_ex(const rtx_scene_desc* desc, int device, uint32_t flags, rtx_scene** out);
 int rtx_scene_destroy(rtx_scene* scene);
 int rtx_scene_device_bytes(const rtx_scene* scene, uint64_t* bytes);

@@ -123,6 +123,7 @@ static long long knob(int k)
     knobs_init();
     return g_knobs[k].value;
 }
+static_assert(sizeof g_knobs / sizeof g_knobs[0] == K_COUNT, "one table entry per knob, in the order of the enum");
 static Knob* find_knob(const char* name)
 {
     knobs_init();
@@ -658,7 +659,7 @@ extern "C" int rtx_scene_create(const rtx_scene_desc* d, int device, rtx_scene**
 extern "C" int rtx_scene_create_ex(const rtx_scene_desc* d, int device, uint32_t flags, rtx_scene** out)
 {
     if (!out) return fail(RTX_E_INVALID, "null output");
-    if (flags & ~RTX_SCENE_F32_TEXTURES) return fail(RTX_E_INVALID, "unknown scene flags 0x%x", flags);
+    if (flags & ~(RTX_SCENE_F32_TEXTURES | RTX_SCENE_SKY_LOOKUP)) return fail(RTX_E_INVALID, "unknown scene flags 0x%x", flags);
     const bool compact_textures = !(flags & RTX_SCENE_F32_TEXTURES);
     *out = nullptr;
     int n = 0, rc;
@@ -901,6 +902,22 @@ extern "C" int rtx_scene_create_ex(const rtx_scene_desc* d, int device, uint32_t
     S.n_nodes = d->n_nodes, S.n_refs = d->n_refs, S.n_tris = d->n_tris, S.n_spheres = d->n_spheres;
     S.n_planes = d->n_planes, S.n_materials = d->n_materials, S.n_textures = d->n_textures, S.root_literal = d->root_index;
     for (int i = 0; i < 6; i++) S.skybox_tex[i] = d->skybox_tex[i];
+    S.sky_1x1 = 0u;
+    for (int i = 0; i < 6; i++) { // single-texel faces: the lookup's answer is known here (see SceneDev)
+        const rtx_texture_desc& td = d->textures[d->skybox_tex[i]];
+        if (td.width == 1 && td.height == 1) {
+            S.sky_1x1 |= 1u << i;
+            for (int c = 0; c < 3; c++) S.sky_rgb[3 * i + c] = d->tex_data[3 * td.offset + c];
+        } else {
+            for (int c = 0; c < 3; c++) S.sky_rgb[3 * i + c] = 0.0f;
+        }
+    }
+    if (S.sky_1x1 == 63u) {
+        bool same = true;
+        for (int i = 1; i < 6; i++) same = same && memcmp(&S.sky_rgb[3 * i], &S.sky_rgb[0], 12) == 0;
+        if (same) S.sky_1x1 |= 64u;
+    }
+    if (flags & RTX_SCENE_SKY_LOOKUP) S.sky_1x1 = 0u; // the full lookup for every face (the tests compare the two)
     UP(noalloc_scratch_address(sc)); // needs cull_useful (set above) to know which kernels this scene launches
 #undef UP
     *out = sc;

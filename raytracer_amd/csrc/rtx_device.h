@@ -91,6 +91,12 @@ struct SceneDev {
     uint32_t                root;         // culled kernel: where a link to the root leads (the root itself unless it is a folded cut-off node)
     uint32_t                root_literal; // literal walk: desc.root_index
     int32_t                 skybox_tex[6];
+    // Faces whose texture is a single texel (Texture_Import_Color, src/gfx/texture.c:49-70: the constant skies of BASELINE
+    // configs 2, 3 and 5): Texture_ColorAt returns that texel whatever u and v are — x = (size_t)(u * 0) — so the lookup
+    // needs neither the two quotients nor the three dependent loads.  sky_1x1: bit f set = face f is such a face and
+    // sky_rgb[3 f ..] holds its texel (the very bits the texture holds); bit 6 = all six are, with the same texel.
+    uint32_t                sky_1x1;
+    float                   sky_rgb[18];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -665,6 +671,7 @@ DEV f3 Texture_ColorAt(const SceneDev& S, int32_t tex, float u, float v)
 
 DEV f3 Skybox_ColorAt(const SceneDev& S, f3 dir)
 {
+    if (S.sky_1x1 & 64u) return mk3(S.sky_rgb[0], S.sky_rgb[1], S.sky_rgb[2]); // one colour all round: any face, any (u, v), NaNs included
     float absX = fabsf(dir.x), absY = fabsf(dir.y), absZ = fabsf(dir.z);
     bool  xp = dir.x > 0, yp = dir.y > 0, zp = dir.z > 0;
     float maxAxis, uc, vc;
@@ -682,6 +689,7 @@ DEV f3 Skybox_ColorAt(const SceneDev& S, f3 dir)
     } else {
         maxAxis = absZ, uc = -dir.x, vc = dir.y, index = 5;
     }
+    if ((S.sky_1x1 >> index) & 1u) return mk3(S.sky_rgb[3 * index], S.sky_rgb[3 * index + 1], S.sky_rgb[3 * index + 2]);
     float u = 0.5f * (uc / maxAxis + 1.0f);
     float v = 0.5f * (vc / maxAxis + 1.0f);
     return Texture_ColorAt(S, S.skybox_tex[index], u, v);

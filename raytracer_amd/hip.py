@@ -22,6 +22,7 @@ EXPORTS = ["rtx_abi_version", "rtx_last_error", "rtx_device_count", "rtx_scene_c
            "rtx_skybox_color", "rtx_kd_build", "rtx_kd_free", "rtx_closest_hit_noalloc", "rtx_cull_node_flags", "rtx_scene_create_ex", "rtx_tune_set", "rtx_tune_get", "rtx_tune_reset", "rtx_render_multi"]
 RTX_SPLIT_TILE, RTX_SPLIT_SAMPLE = 0, 1
 RTX_SCENE_F32_TEXTURES = 1
+RTX_SCENE_SKY_LOOKUP = 2
 RTX_NOALLOC_MAX_RAYS = 1 << 18
 
 _lib = None

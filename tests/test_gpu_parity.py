@@ -719,6 +719,25 @@ def test_compact_textures_are_lossless(built_scenes, device_scenes):
         assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1]) and a[2]["rays_at_depth"] == b[2]["rays_at_depth"]
 
 
+@pytest.mark.parametrize("scene", ["dragon1", "bunny", "materials"])
+def test_single_texel_sky_faces_answered_without_the_lookup(built_scenes, device_scenes, scene):
+    """A skybox face of one texel (the constant skies of BASELINE configs 2, 3, 5) is answered from the scene block instead of
+    through Skybox_ColorAt's quotients and Texture_ColorAt's loads (skybox.c:66-134, texture.c:88-95: x = (size_t)(u * 0)).
+    Same lookups — every direction incl. zeros, infinities and NaNs — and the same frames, bit for bit, as with the full
+    lookup for every face (RTX_SCENE_SKY_LOOKUP); materials has a cube map of real images: nothing changes there."""
+    sc, fast = built_scenes(scene), device_scenes(scene)
+    with hip.DeviceScene(sc.desc, 0, flags=hip.RTX_SCENE_SKY_LOOKUP) as full:
+        rng = np.random.default_rng(5)
+        dirs = rng.normal(size=(20000, 3)).astype(np.float32)
+        dirs[:6] = np.eye(3, dtype=np.float32).repeat(2, 0) * np.array([1, -1] * 3, np.float32)[:, None]
+        dirs[6:10] = [[0, 0, 0], [np.nan, 1, 0], [np.inf, 0, 1], [-np.inf, np.inf, 0]]
+        dirs[10:16] = [[1, 1, 0], [1, -1, 0], [-1, 0, 1], [0, 1, 1], [1, 1, 1], [-1, -1, -1]]
+        assert same_values(fast.skybox_color(dirs), full.skybox_color(dirs))
+        p = hip.make_params(200, 112, 4, 8, seed=(7, 9))
+        a, b = fast.render(sc.rtx_camera(), p), full.render(sc.rtx_camera(), p)
+        assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1]) and a[2]["rays_at_depth"] == b[2]["rays_at_depth"]
+
+
 CULLED_SEEDS = {0, 1, 2, 3, 4, 7, 8, 9, 10}  # the soups whose default kernel is the culled walk and culls something (from a run)
 
 
