@@ -54,38 +54,20 @@ DEV float kd_surface_area(const float lo[3], const float hi[3]) // kdtree.c:198-
 }
 
 // KD_BLOCK: 256 threads per node on wide levels, 1024 on the narrow top levels, whose lists are long
+// A long list cut into segments of KD_SEG references, one block each (the narrow top levels: the root's list is every
+// primitive of the scene, and one block per NODE left 255 of the 256 CUs idle for a third of the build's time)
+#define KD_SEG 4096u
+#define KD_HIST_WORDS (3 * (KD_MAX_CAND + 2)) // per node and histogram
+struct KdSeg {
+    uint32_t node, begin, count, first; // node of the level, range within its list, index of the node's first segment
+};
+
+// one pass over references [i0, i1) of a node's list: a = #{planes <= box.max}, g = #{planes < box.min} per axis, into LDS
 template <int KD_BLOCK>
-__global__ __launch_bounds__(KD_BLOCK) void k_kd_decide(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs,
-                                                        const float* __restrict__ boxes, uint32_t depth_left,
-                                                        KdDecision* __restrict__ out)
+DEV void kd_histogram_pass(const KdNode& nd, const uint32_t* __restrict__ refs, const float* __restrict__ boxes, uint32_t i0, uint32_t i1,
+                           const float (*s_cand)[KD_MAX_CAND], const int* s_k, uint32_t (*s_a)[KD_MAX_CAND + 2], uint32_t (*s_g)[KD_MAX_CAND + 2])
 {
-    __shared__ float    s_cand[3][KD_MAX_CAND];
-    __shared__ int      s_k[3];
-    __shared__ uint32_t s_a[3][KD_MAX_CAND + 2], s_g[3][KD_MAX_CAND + 2]; // histograms, then their prefix sums
-    __shared__ float    s_sah[3][KD_MAX_CAND];
-    const KdNode   nd  = nodes[blockIdx.x];
-    const uint32_t n   = nd.ref_count;
-    const uint32_t tid = threadIdx.x;
-    if (n <= KD_MIN_LEAF_LOAD || depth_left == 0u) { // kdtree.c:286
-        if (tid == 0) out[blockIdx.x] = KdDecision{n, 3u, 0u, 0u};
-        return;
-    }
-    for (uint32_t i = tid; i < 3 * (KD_MAX_CAND + 2); i += KD_BLOCK) (&s_a[0][0])[i] = 0u, (&s_g[0][0])[i] = 0u;
-    if (tid < 3) { // candidate planes of one axis: kdtree.c:299-301, `bucket += stride` in f32
-        const float cmin = nd.lo[tid], cmax = nd.hi[tid];
-        const float stride = (cmax - cmin) / KD_NUM_BUCKETS;
-        int         k = 0;
-        if (stride > 0.0f && cmin + stride != cmin) {
-            for (float bucket = cmin + stride; bucket <= cmax - stride; bucket += stride) {
-                if (k == KD_MAX_CAND) break;
-                s_cand[tid][k++] = bucket;
-            }
-        }
-        s_k[tid] = k;
-    }
-    __syncthreads();
-    // one pass over the primitives: a = #{planes <= box.max}, g = #{planes < box.min} per axis
-    for (uint32_t i = tid; i < n; i += KD_BLOCK) {
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += KD_BLOCK) {
         const float* bx = boxes + 6ull * refs[nd.ref_begin + i];
         for (int axis = 0; axis < 3; axis++) {
             const int k = s_k[axis];
@@ -105,6 +87,75 @@ __global__ __launch_bounds__(KD_BLOCK) void k_kd_decide(const KdNode* __restrict
             atomicAdd(&s_g[axis][g], 1u);
         }
     }
+}
+
+// candidate planes of one axis (thread `axis` of the block): kdtree.c:299-301, `bucket += stride` in f32
+DEV void kd_candidates(const KdNode& nd, int axis, float (*s_cand)[KD_MAX_CAND], int* s_k)
+{
+    const float cmin = nd.lo[axis], cmax = nd.hi[axis];
+    const float stride = (cmax - cmin) / KD_NUM_BUCKETS;
+    int         k = 0;
+    if (stride > 0.0f && cmin + stride != cmin) {
+        for (float bucket = cmin + stride; bucket <= cmax - stride; bucket += stride) {
+            if (k == KD_MAX_CAND) break;
+            s_cand[axis][k++] = bucket;
+        }
+    }
+    s_k[axis] = k;
+}
+
+// narrow levels, first half of k_kd_decide's work: the histograms of ONE SEGMENT of a node's list, added to the node's
+// histograms in global memory (integer counts: the order of the additions does not matter)
+__global__ __launch_bounds__(1024) void k_kd_hist_seg(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs, const float* __restrict__ boxes,
+                                                      const KdSeg* __restrict__ segs, uint32_t depth_left, uint32_t* __restrict__ g_hist)
+{
+    __shared__ float    s_cand[3][KD_MAX_CAND];
+    __shared__ int      s_k[3];
+    __shared__ uint32_t s_a[3][KD_MAX_CAND + 2], s_g[3][KD_MAX_CAND + 2];
+    const KdSeg    sg  = segs[blockIdx.x];
+    const KdNode   nd  = nodes[sg.node];
+    const uint32_t tid = threadIdx.x;
+    if (nd.ref_count <= KD_MIN_LEAF_LOAD || depth_left == 0u) return; // a leaf by rule (kdtree.c:286): k_kd_decide says so
+    for (uint32_t i = tid; i < KD_HIST_WORDS; i += 1024) (&s_a[0][0])[i] = 0u, (&s_g[0][0])[i] = 0u;
+    if (tid < 3) kd_candidates(nd, (int)tid, s_cand, s_k);
+    __syncthreads();
+    kd_histogram_pass<1024>(nd, refs, boxes, sg.begin, sg.begin + sg.count, s_cand, s_k, s_a, s_g);
+    __syncthreads();
+    uint32_t* h = g_hist + 2ull * KD_HIST_WORDS * sg.node;
+    for (uint32_t i = tid; i < KD_HIST_WORDS; i += 1024) {
+        const uint32_t a = (&s_a[0][0])[i], g = (&s_g[0][0])[i];
+        if (a) atomicAdd(h + i, a);
+        if (g) atomicAdd(h + KD_HIST_WORDS + i, g);
+    }
+}
+
+// g_hist != nullptr: the node's histograms have been counted by k_kd_hist_seg (narrow levels); else they are counted here
+template <int KD_BLOCK>
+__global__ __launch_bounds__(KD_BLOCK) void k_kd_decide(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs,
+                                                        const float* __restrict__ boxes, uint32_t depth_left,
+                                                        KdDecision* __restrict__ out, const uint32_t* __restrict__ g_hist)
+{
+    __shared__ float    s_cand[3][KD_MAX_CAND];
+    __shared__ int      s_k[3];
+    __shared__ uint32_t s_a[3][KD_MAX_CAND + 2], s_g[3][KD_MAX_CAND + 2]; // histograms, then their prefix sums
+    __shared__ float    s_sah[3][KD_MAX_CAND];
+    const KdNode   nd  = nodes[blockIdx.x];
+    const uint32_t n   = nd.ref_count;
+    const uint32_t tid = threadIdx.x;
+    if (n <= KD_MIN_LEAF_LOAD || depth_left == 0u) { // kdtree.c:286
+        if (tid == 0) out[blockIdx.x] = KdDecision{n, 3u, 0u, 0u};
+        return;
+    }
+    if (g_hist) {
+        const uint32_t* h = g_hist + 2ull * KD_HIST_WORDS * blockIdx.x;
+        for (uint32_t i = tid; i < KD_HIST_WORDS; i += KD_BLOCK) (&s_a[0][0])[i] = h[i], (&s_g[0][0])[i] = h[KD_HIST_WORDS + i];
+    } else {
+        for (uint32_t i = tid; i < KD_HIST_WORDS; i += KD_BLOCK) (&s_a[0][0])[i] = 0u, (&s_g[0][0])[i] = 0u;
+    }
+    if (tid < 3) kd_candidates(nd, (int)tid, s_cand, s_k);
+    __syncthreads();
+    // one pass over the primitives: a = #{planes <= box.max}, g = #{planes < box.min} per axis
+    if (!g_hist) kd_histogram_pass<KD_BLOCK>(nd, refs, boxes, 0u, n, s_cand, s_k, s_a, s_g);
     __syncthreads();
     if (tid < 3) { // inclusive prefix sums: s_a[j] = #{box.max < plane j}, s_g[j] = #{box.min <= plane j}
         uint32_t ra = 0, rg = 0;
@@ -243,6 +294,96 @@ __global__ __launch_bounds__(KD_BLOCK) void k_kd_emit(const KdNode* __restrict__
     }
 }
 
+// narrow levels, k_kd_emit by segments.  First the number of references a segment sends left and right ...
+__global__ __launch_bounds__(1024) void k_kd_count_seg(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs, const float* __restrict__ boxes,
+                                                       const KdDecision* __restrict__ dec, const KdSeg* __restrict__ segs, uint2* __restrict__ seg_cnt)
+{
+    __shared__ uint32_t s_l, s_r;
+    const KdSeg      sg = segs[blockIdx.x];
+    const KdNode     nd = nodes[sg.node];
+    const KdDecision d  = dec[sg.node];
+    if (threadIdx.x == 0) s_l = 0u, s_r = 0u;
+    __syncthreads();
+    if (d.axis != 3u) {
+        const float split = __uint_as_float(d.split_bits);
+        uint32_t    cl = 0, cr = 0;
+        for (uint32_t i = sg.begin + threadIdx.x; i < sg.begin + sg.count; i += 1024) {
+            const float* bx = boxes + 6ull * refs[nd.ref_begin + i];
+            const float  bmin = bx[d.axis], bmax = bx[3 + d.axis];
+            if (bmax < split) cl++;
+            else if (bmin > split) cr++;
+            else cl++, cr++;
+        }
+        for (int off = 32; off > 0; off >>= 1) cl += __shfl_down(cl, off), cr += __shfl_down(cr, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_l, cl), atomicAdd(&s_r, cr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[blockIdx.x] = make_uint2(s_l, s_r);
+}
+
+// ... then the stable partition (kdtree.c:331-347), every segment starting behind what the node's earlier segments send
+__global__ __launch_bounds__(1024) void k_kd_emit_seg(const KdNode* __restrict__ nodes, const uint32_t* __restrict__ refs, const float* __restrict__ boxes,
+                                                      const KdDecision* __restrict__ dec, const uint32_t* __restrict__ off, uint32_t m, KdTopo* __restrict__ topo,
+                                                      uint32_t topo_base, uint32_t next_base, uint32_t* __restrict__ leaf_pool, uint32_t leaf_base,
+                                                      KdNode* __restrict__ next_nodes, uint32_t* __restrict__ next_refs, const KdSeg* __restrict__ segs,
+                                                      const uint2* __restrict__ seg_cnt)
+{
+    __shared__ uint32_t s_wl[16], s_wr[16];
+    const KdSeg      sg  = segs[blockIdx.x];
+    const uint32_t   b   = sg.node, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const KdNode     nd  = nodes[b];
+    const KdDecision d   = dec[b];
+    const uint32_t   n   = nd.ref_count;
+    const bool       head = blockIdx.x == sg.first; // the node's first segment writes the node itself
+    if (d.axis == 3u) { // BuildLeafNode, kdtree.c:173-196
+        const uint32_t at = leaf_base + off[2ull * m + b];
+        for (uint32_t i = sg.begin + tid; i < sg.begin + sg.count; i += 1024) leaf_pool[at + i] = refs[nd.ref_begin + i];
+        if (head && tid == 0) topo[topo_base + b] = KdTopo{n, 3u, at, 0u};
+        return;
+    }
+    const uint32_t child  = off[b];
+    const uint32_t rbegin = off[1ull * m + b], lbegin = rbegin + d.n_right;
+    const float    split  = __uint_as_float(d.split_bits);
+    if (head && tid == 0) {
+        topo[topo_base + b] = KdTopo{d.split_bits, d.axis, next_base + child + 1u, 0u};
+        KdNode r = nd, l = nd;
+        r.lo[d.axis] = split, l.hi[d.axis] = split; // SplitBox
+        r.ref_begin = rbegin, r.ref_count = d.n_right;
+        l.ref_begin = lbegin, l.ref_count = d.n_left;
+        next_nodes[child]     = r;
+        next_nodes[child + 1] = l;
+    }
+    uint32_t doneL = 0, doneR = 0; // block-uniform: what the node's earlier segments send left and right
+    for (uint32_t q = sg.first; q < blockIdx.x; q++) doneL += seg_cnt[q].x, doneR += seg_cnt[q].y;
+    for (uint32_t base = sg.begin; base < sg.begin + sg.count; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t       r = 0;
+        bool           fl = false, fr = false;
+        if (i < sg.begin + sg.count) {
+            r               = refs[nd.ref_begin + i];
+            const float* bx = boxes + 6ull * r;
+            const float  bmin = bx[d.axis], bmax = bx[3 + d.axis];
+            if (bmax < split) fl = true;
+            else if (bmin > split) fr = true;
+            else fl = fr = true;
+        }
+        const uint64_t ml = __ballot(fl), mr = __ballot(fr);
+        const uint64_t lt = (1ull << lane) - 1ull;
+        if (lane == 0) s_wl[wave] = (uint32_t)__popcll(ml), s_wr[wave] = (uint32_t)__popcll(mr);
+        __syncthreads();
+        uint32_t pl = doneL + (uint32_t)__popcll(ml & lt), pr = doneR + (uint32_t)__popcll(mr & lt);
+        uint32_t tl = 0, tr = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) pl += s_wl[w], pr += s_wr[w];
+            tl += s_wl[w], tr += s_wr[w];
+        }
+        if (fl && pl < d.n_left) next_refs[lbegin + pl] = r;
+        if (fr && pr < d.n_right) next_refs[rbegin + pr] = r;
+        doneL += tl, doneR += tr;
+        __syncthreads();
+    }
+}
+
 // a device array that grows (contents kept)
 struct KdBuf {
     void*  p     = nullptr;
@@ -297,7 +438,7 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
     HIPCHECK(hipSetDevice(device));
     const double t0 = kd_now_ms();
 
-    KdBuf boxes, nodes[2], refs[2], dec, off, totals, topo, pool;
+    KdBuf boxes, nodes[2], refs[2], dec, off, totals, topo, pool, segs, seg_cnt, hist;
     HIPCHECK(boxes.need(n * 24, 0));
     HIPCHECK(hipMemcpy(boxes.p, box_min_max, n * 24, hipMemcpyHostToDevice));
     HIPCHECK(totals.need(3 * sizeof(uint64_t), 0));
@@ -313,7 +454,7 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
         HIPCHECK(hipMemcpy(refs[0].p, all.data(), n * 4, hipMemcpyHostToDevice));
     }
     const double t1 = kd_now_ms();
-    uint64_t m = 1, n_topo = 0, n_pool = 0, level = 0;
+    uint64_t m = 1, n_topo = 0, n_pool = 0, level = 0, level_refs = n; // level_refs: references in the lists of the level
     int      cur = 0;
     for (;; level++) {
         if (m > 0x7FFFFFFFull) return fail(RTX_E_LIMIT, "rtx_kd_build: level too wide");
@@ -322,8 +463,37 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
         HIPCHECK(topo.need((n_topo + m) * sizeof(KdTopo), n_topo * sizeof(KdTopo)));
         const uint32_t depth_left = (uint32_t)(max_depth > level ? max_depth - level : 0);
         const bool narrow = m <= 4096; // few nodes, long lists: four times the threads per node
-        hipLaunchKernelGGL(narrow ? k_kd_decide<1024> : k_kd_decide<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
-                           refs[cur].as<uint32_t>(), boxes.as<float>(), depth_left, dec.as<KdDecision>());
+        // The top levels — a handful of nodes with lists of tens of thousands of references — are cut into segments of KD_SEG
+        // references, a block each, instead of one block per node (root of the 278 k-triangle stand-in: 0.8 ms on one CU).
+        std::vector<KdSeg> sv;
+        if (m <= 512 && level_refs > 2ull * KD_SEG * m / 4 + KD_SEG) {
+            std::vector<KdNode> hn(m);
+            HIPCHECK(hipMemcpy(hn.data(), nodes[cur].p, m * sizeof(KdNode), hipMemcpyDeviceToHost));
+            uint32_t longest = 0;
+            for (const KdNode& k : hn) longest = std::max(longest, k.ref_count);
+            if (longest > 2 * KD_SEG) {
+                for (uint32_t b = 0; b < (uint32_t)m; b++) {
+                    const uint32_t first = (uint32_t)sv.size(), cnt = hn[b].ref_count;
+                    if (cnt == 0) sv.push_back(KdSeg{b, 0u, 0u, first});
+                    for (uint32_t at = 0; at < cnt; at += KD_SEG) sv.push_back(KdSeg{b, at, std::min(KD_SEG, cnt - at), first});
+                }
+            }
+        }
+        const bool segmented = !sv.empty();
+        if (segmented) {
+            HIPCHECK(segs.need(sv.size() * sizeof(KdSeg), 0));
+            HIPCHECK(seg_cnt.need(sv.size() * sizeof(uint2), 0));
+            HIPCHECK(hist.need(m * 2ull * KD_HIST_WORDS * 4, 0));
+            HIPCHECK(hipMemcpy(segs.p, sv.data(), sv.size() * sizeof(KdSeg), hipMemcpyHostToDevice));
+            HIPCHECK(hipMemsetAsync(hist.p, 0, m * 2ull * KD_HIST_WORDS * 4, 0));
+            hipLaunchKernelGGL(k_kd_hist_seg, dim3((unsigned)sv.size()), dim3(1024), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(),
+                               segs.as<KdSeg>(), depth_left, hist.as<uint32_t>());
+            hipLaunchKernelGGL(k_kd_decide<256>, dim3((unsigned)m), dim3(256), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(), depth_left,
+                               dec.as<KdDecision>(), (const uint32_t*)hist.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(narrow ? k_kd_decide<1024> : k_kd_decide<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
+                               refs[cur].as<uint32_t>(), boxes.as<float>(), depth_left, dec.as<KdDecision>(), (const uint32_t*)nullptr);
+        }
         hipLaunchKernelGGL(k_kd_scan, dim3(1), dim3(1024), 0, 0, dec.as<KdDecision>(), (uint32_t)m, off.as<uint32_t>(), totals.as<uint64_t>());
         HIPCHECK(hipGetLastError());
         uint64_t tot[3];
@@ -333,11 +503,21 @@ extern "C" int rtx_kd_build(int device, const float* box_min_max, uint64_t n, ui
         HIPCHECK(nodes[cur ^ 1].need(std::max<uint64_t>(tot[0], 1) * sizeof(KdNode), 0));
         HIPCHECK(refs[cur ^ 1].need(std::max<uint64_t>(tot[1], 1) * 4, 0));
         HIPCHECK(pool.need(std::max<uint64_t>(n_pool + tot[2], 1) * 4, n_pool * 4));
-        hipLaunchKernelGGL(narrow ? k_kd_emit<1024> : k_kd_emit<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
-                           refs[cur].as<uint32_t>(), boxes.as<float>(),
-                           dec.as<KdDecision>(), off.as<uint32_t>(), (uint32_t)m, topo.as<KdTopo>(), (uint32_t)n_topo, (uint32_t)(n_topo + m),
-                           pool.as<uint32_t>(), (uint32_t)n_pool, nodes[cur ^ 1].as<KdNode>(), refs[cur ^ 1].as<uint32_t>());
+        if (segmented) {
+            hipLaunchKernelGGL(k_kd_count_seg, dim3((unsigned)sv.size()), dim3(1024), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(),
+                               dec.as<KdDecision>(), segs.as<KdSeg>(), seg_cnt.as<uint2>());
+            hipLaunchKernelGGL(k_kd_emit_seg, dim3((unsigned)sv.size()), dim3(1024), 0, 0, nodes[cur].as<KdNode>(), refs[cur].as<uint32_t>(), boxes.as<float>(),
+                               dec.as<KdDecision>(), off.as<uint32_t>(), (uint32_t)m, topo.as<KdTopo>(), (uint32_t)n_topo, (uint32_t)(n_topo + m),
+                               pool.as<uint32_t>(), (uint32_t)n_pool, nodes[cur ^ 1].as<KdNode>(), refs[cur ^ 1].as<uint32_t>(), segs.as<KdSeg>(),
+                               seg_cnt.as<uint2>());
+        } else {
+            hipLaunchKernelGGL(narrow ? k_kd_emit<1024> : k_kd_emit<256>, dim3((unsigned)m), dim3(narrow ? 1024 : 256), 0, 0, nodes[cur].as<KdNode>(),
+                               refs[cur].as<uint32_t>(), boxes.as<float>(),
+                               dec.as<KdDecision>(), off.as<uint32_t>(), (uint32_t)m, topo.as<KdTopo>(), (uint32_t)n_topo, (uint32_t)(n_topo + m),
+                               pool.as<uint32_t>(), (uint32_t)n_pool, nodes[cur ^ 1].as<KdNode>(), refs[cur ^ 1].as<uint32_t>());
+        }
         HIPCHECK(hipGetLastError());
+        level_refs = tot[1];
         n_topo += m;
         n_pool += tot[2];
         if (tot[0] == 0) break;
