@@ -322,7 +322,7 @@ def main():
                                                "raygen": v[10] / args.steps / world, "resolve": v[11] / args.steps / world,
                                                "ray_binning": v[13] / args.steps / world}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace_flat<false,true,true,false>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
+                         "traffic": traffic, "kernel": "k_trace_flat<false,true,true,false,false>", "alg_bytes_per_launch": alg_per_launch, "ms_per_launch": ms_per_launch,
                          "alg_bytes_per_ray": bytes_frame / rays_frame, "requested_bytes_per_ray_with_child_boxes": v[14] / rays_frame,
                          # rocprofv3 --pmc passes of this same command (profiles/, tools/profile_round.sh): HBM-side GB/s of the
                          # kernel, L2 (TCC) hit rate, share of SIMD cycles issuing vector instructions, active lanes per instruction
